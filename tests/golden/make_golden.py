@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference's own host code.
+
+Run in the container that mounts the reference tree (it builds oracle/_ref/libck_ref.so from
+the reference headers and calls it through ctypes).  The outputs are plain ``.npz`` files holding
+inputs and the reference's outputs only -- data, no code -- and are committed, so the parity
+tests also run where the reference is absent (the GPU box).
+
+    python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import binding  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def f16_bits(x: np.ndarray) -> np.ndarray:
+    return np.asarray(x, dtype=np.float16).view(np.uint16)
+
+
+def bf16_bits_trunc(x: np.ndarray) -> np.ndarray:
+    return (np.asarray(x, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def scalars(ref) -> dict:
+    rng = np.random.default_rng(20250301)
+    out = {}
+    # fp16 dequant: every int8 value x a spread of scales (incl. subnormal / large / negative)
+    scales = np.concatenate([
+        f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, 24)),
+        f16_bits(rng.uniform(-1, 1, 16)),
+        np.array([0x3555, 0x2E66, 0xB99A, 0x0400, 0x0001, 0x03FF, 0x7BFF, 0x3C00, 0xBC00, 0x0000], np.uint16),
+    ]).astype(np.uint16)
+    q = np.arange(-128, 128, dtype=np.int16)
+    out["dequant_f16_scales"] = scales
+    out["dequant_f16"] = np.array([[ref.dequant_f16(int(v), int(s)) for v in q] for s in scales], np.uint16)
+    bscales = np.concatenate([
+        bf16_bits_trunc(rng.uniform(2.0 ** -8, 2.0 ** -4, 24)),
+        bf16_bits_trunc(rng.uniform(-2, 2, 16)),
+        np.array([0x3EAB, 0x3F9A, 0x3C23, 0x3F80, 0x0080, 0x7F7F], np.uint16),
+    ]).astype(np.uint16)
+    out["multiply_bf16_scales"] = bscales
+    out["multiply_bf16"] = np.array([[ref.multiply_bf16(int(v), int(s)) for v in q] for s in bscales], np.uint16)
+    # conversions
+    fx = np.concatenate([
+        rng.uniform(-1, 1, 512) * rng.choice([1e-8, 1e-6, 6e-5, 1e-3, 1.0, 100.0, 7e4], 512),
+        np.array([0.0, -0.0, 65504.0, 65519.99, 65520.0, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001,
+                  2.0 ** -14, 1.00048828125, 1.0009765625 + 2.0 ** -11]),
+    ]).astype(np.float32)
+    out["f32_in"] = fx
+    out["f32_to_f16"] = np.array([ref.f32_to_f16(float(v)) for v in fx], np.uint16)
+    out["f32_to_bf16"] = np.array([ref.f32_to_bf16(float(v)) for v in fx], np.uint16)
+    out["f16_to_f32"] = np.array([ref.f16_to_f32(h) for h in range(0, 65536, 7)], np.float32)
+    out["f8_to_f32"] = np.array([ref.f8_to_f32(v) for v in range(256)], np.float32)
+    # FastGelu host <float,float>
+    gx = np.concatenate([rng.normal(size=1024) * 3.0, np.array([-3, -1, 0.5, 1, 3, 10, 0, -20, 20])]).astype(np.float32)
+    out["fastgelu_in"] = gx
+    out["fastgelu"] = np.array([ref.fastgelu(float(v)) for v in gx], np.float32)
+    # Activation_Mul_Clamp(0.03) over accumulator values (int32 form and float-accumulator form)
+    acc = np.concatenate([np.arange(-4400, 4400, 7), np.array([33, 34, -34, 50, 84, 4233, 4234, -4266, -4267,
+                                                                100000, -100000, 2 ** 24, -(2 ** 24)])]).astype(np.int32)
+    out["amc_in"] = acc
+    out["amc_0p03"] = np.array([ref.act_mul_clamp(0.03, int(v)) for v in acc], np.int8)
+    out["amc_from_float_0p03"] = np.array([ref.act_mul_clamp_from_float(0.03, float(v)) for v in acc], np.int8)
+    # MultiplyMultiply / MultiplyAddFastGelu
+    c = rng.normal(size=256).astype(np.float32) * 50
+    d0 = rng.uniform(0, 1, 256).astype(np.float32)
+    d1 = rng.uniform(0, 1, 256).astype(np.float32)
+    out["mm_c"], out["mm_d0"], out["mm_d1"] = c, d0, d1
+    out["mm_f16"] = np.array([ref.multiply_multiply_f16(float(a), float(b), float(e)) for a, b, e in zip(c, d0, d1)], np.uint16)
+    out["mm_bf16"] = np.array([ref.multiply_multiply_bf16(float(a), float(b), float(e)) for a, b, e in zip(c, d0, d1)], np.uint16)
+    b0 = bf16_bits_trunc(d0)
+    b1 = bf16_bits_trunc(d1 - 0.5)
+    out["mafg_d0"], out["mafg_d1"] = b0, b1
+    out["mafg_bf16"] = np.array([ref.multiply_add_fastgelu_bf16(float(a), int(x), int(y)) for a, x, y in zip(c, b0, b1)], np.uint16)
+    # generators: first values of every (dtype, mode) the drivers use
+    for dt in ("f16", "bf16", "i8", "f32"):
+        for iv in (0, 1):
+            out[f"fill_{dt}_{iv}"] = ref.fill_uniform(96, dt, -1.0, 1.0, bool(iv))
+    out["fill_i8_int4range"] = ref.fill_uniform(96, "i8", -8.0, 7.0, True)
+    out["gen2_i8_seed1"] = ref.generator2_i8(8, 12, 12, 1, -128, 127, seed=1)
+    out["gen2_i8_seed1_col"] = ref.generator2_i8(8, 12, 1, 8, -5, 5, seed=1)
+    return out
+
+
+def gemm_cases(ref) -> dict:
+    rng = np.random.default_rng(11939)
+    out = {}
+
+    # ---- fp16 A x int4-range B (config C2 semantics, small) ---------------------------------
+    def fpaintb(tag, M, N, K, lda, ldb, ldc, integer, qlo, qhi):
+        if integer:
+            a = f16_bits(np.round(rng.uniform(-1, 1, (M, lda))))
+            s = f16_bits(rng.integers(1, 4, N).astype(np.float32))
+        else:
+            a = f16_bits(rng.uniform(-1, 1, (M, lda)))
+            s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+        b = rng.integers(qlo, qhi + 1, (N, ldb)).astype(np.int8)  # column-major (K,N): row n holds K values
+        c = ref.fpAintB_gemm_f16(a, b, s, M, N, K, lda, ldb, ldc)
+        out[f"{tag}_shape"] = np.array([M, N, K, lda, ldb, ldc], np.int32)
+        out[f"{tag}_a"], out[f"{tag}_b"], out[f"{tag}_s"], out[f"{tag}_c"] = a, b, s, c
+
+    fpaintb("fpaintb_real", 64, 48, 128, 128, 128, 48, False, -8, 7)
+    fpaintb("fpaintb_int", 128, 128, 256, 256, 256, 128, True, -8, 7)
+    fpaintb("fpaintb_ragged", 33, 17, 72, 80, 88, 24, False, -8, 7)
+    fpaintb("fpaintb_i8", 48, 32, 64, 64, 64, 32, False, -128, 127)
+
+    # example/64 exactly (init_method 1 and 2, tiny): A, quant B and scale each from a fresh
+    # mt19937(11939) -- run_gemm_example.inc:36-49
+    for init in (1, 2):
+        M, N, K = 32, 32, 64
+        a = ref.fill_uniform(M * K, "f16", -1.0, 1.0, init == 1).reshape(M, K)
+        b = ref.fill_uniform(K * N, "i8", -1.0, 1.0, init == 1).reshape(N, K)
+        s = ref.fill_uniform(N, "f16", -1.0, 1.0, init == 1)
+        out[f"ex64_init{init}_c"] = ref.fpAintB_gemm_f16(a, b, s, M, N, K, K, K, N)
+
+    # ---- C1: example/14 host verify path, M=N=K=256, srand(1), GeneratorTensor_2{-128,127} ---
+    M = N = K = 256
+    a = ref.generator2_i8(M, K, K, 1, -128, 127, seed=1)      # row-major A, drawn first
+    b = ref.generator2_i8(K, N, 1, K, -128, 127, seed=-1)     # column-major B continues the stream
+    e = ref.gemm_i8_requant(a, b, M, N, K, K, K, N, 0.03)
+    out["c1_a_head"], out["c1_b_head"] = a[:64].copy(), b[:64].copy()
+    out["c1_e"] = e.reshape(M, N)
+
+    # a second int8 case with small values and ragged strides
+    M, N, K = 40, 24, 96
+    a = rng.integers(-5, 6, (M, 104)).astype(np.int8)
+    b = rng.integers(-5, 6, (N, 100)).astype(np.int8)
+    out["i8_small_a"], out["i8_small_b"] = a, b
+    out["i8_small_e"] = ref.gemm_i8_requant(a, b, M, N, K, 104, 100, 32, 0.25)
+
+    # ---- bf16 A x int8 B (config C3 semantics, small), three epilogues, both B layouts -------
+    M, N, K = 48, 64, 128
+    a = bf16_bits_trunc(rng.uniform(-1, 1, (M, K)))
+    s = bf16_bits_trunc(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    bcol = rng.integers(-128, 128, (N, K)).astype(np.int8)    # (k,n) at n*K + k
+    brow = np.ascontiguousarray(bcol.T)                        # (k,n) at k*N + n
+    d0 = bf16_bits_trunc(rng.uniform(0.5, 1.5, N))
+    d1 = bf16_bits_trunc(rng.uniform(-0.5, 0.5, N))
+    out["bf16_a"], out["bf16_s"], out["bf16_bcol"], out["bf16_d0"], out["bf16_d1"] = a, s, bcol, d0, d1
+    for ep in (0, 1, 2):
+        out[f"bf16_e_col_ep{ep}"] = ref.gemm_bf16_i8(a, bcol, s, M, N, K, K, 1, K, N, ep, d0, d1)
+    out["bf16_e_row_ep1"] = ref.gemm_bf16_i8(a, brow, s, M, N, K, K, N, 1, N, 1, d0, d1)
+
+    # ---- fp8 (FNUZ bytes) A x int4-range B + MultiplyMultiply (+FastGelu) (config C5, small) --
+    M, N, K = 48, 64, 128
+    a8 = rng.integers(0, 256, (M, K)).astype(np.uint8)
+    a8[(a8 == 0x80) | (a8 == 0x7F) | (a8 == 0xFF)] = 0x38     # input contract: no NaN / +-max codes
+    a8 = np.where((a8 & 0x7F) > 0x57, a8 & 0xBF, a8).astype(np.uint8)  # keep |a| modest
+    b4 = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    f0 = rng.uniform(0, 1, N).astype(np.float32)
+    f1 = rng.uniform(0, 1, M).astype(np.float32)
+    out["f8_a"], out["f8_b"], out["f8_d0"], out["f8_d1"] = a8, b4, f0, f1
+    out["f8_e_mm"] = ref.gemm_f8_i8_mm(a8, b4, f0, f1, M, N, K, K, K, N, False)
+    out["f8_e_mm_gelu"] = ref.gemm_f8_i8_mm(a8, b4, f0, f1, M, N, K, K, K, N, True)
+    return out
+
+
+def main() -> None:
+    ref = binding.load_ref()
+    if ref is None:
+        raise SystemExit("reference tree not mounted: cannot regenerate golden vectors")
+    np.savez_compressed(os.path.join(OUT, "scalars.npz"), **scalars(ref))
+    np.savez_compressed(os.path.join(OUT, "gemm_cases.npz"), **gemm_cases(ref))
+    for f in ("scalars.npz", "gemm_cases.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""The plain-C checker (oracle/wq_oracle.c) against golden vectors produced by the reference's
+own host code (tests/golden/make_golden.py).  Bit-exact everywhere: these are integer / bit-level
+results or fp32 loops with a fixed evaluation order."""
+import numpy as np
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.uint32)
+
+
+def test_dequant_f16_table(port, golden_scalars):
+    g = golden_scalars
+    q = np.arange(-128, 128)
+    for s, row in zip(g["dequant_f16_scales"], g["dequant_f16"]):
+        got = np.array([port.dequant_f16(int(v), int(s)) for v in q], np.uint16)
+        np.testing.assert_array_equal(got, row)
+
+
+def test_multiply_bf16_table(port, golden_scalars):
+    g = golden_scalars
+    q = np.arange(-128, 128)
+    for s, row in zip(g["multiply_bf16_scales"], g["multiply_bf16"]):
+        got = np.array([port.multiply_bf16(int(v), int(s)) for v in q], np.uint16)
+        np.testing.assert_array_equal(got, row)
+
+
+def test_conversions(port, golden_scalars):
+    g = golden_scalars
+    fx = g["f32_in"]
+    np.testing.assert_array_equal(np.array([port.f32_to_f16(float(v)) for v in fx], np.uint16), g["f32_to_f16"])
+    np.testing.assert_array_equal(np.array([port.f32_to_bf16(float(v)) for v in fx], np.uint16), g["f32_to_bf16"])
+    got = np.array([port.f16_to_f32(h) for h in range(0, 65536, 7)], np.float32)
+    exp = g["f16_to_f32"]
+    nan = np.isnan(exp)
+    assert np.array_equal(np.isnan(got), nan)
+    np.testing.assert_array_equal(_bits(got[~nan]), _bits(exp[~nan]))
+
+
+def test_f8_fnuz_table(port, golden_scalars):
+    exp = golden_scalars["f8_to_f32"]
+    got = np.array([port.f8_to_f32(v) for v in range(256)], np.float32)
+    assert np.isnan(got[0x80]) and np.isnan(exp[0x80])
+    m = np.arange(256) != 0x80
+    np.testing.assert_array_equal(_bits(got[m]), _bits(exp[m]))
+    # known answers held by the reference's own test (test/data_type/test_fp8.cpp:13-54)
+    assert got[0x08] == 2.0 ** -7 and got[0x7F] == 240.0 and got[0xFF] == -240.0
+    assert got[0x01] == 2.0 ** -10 and got[0x40] == 1.0 and got[0xC0] == -1.0
+
+
+def test_fastgelu(port, golden_scalars):
+    g = golden_scalars
+    got = np.array([port.fastgelu(float(v)) for v in g["fastgelu_in"]], np.float32)
+    np.testing.assert_array_equal(_bits(got), _bits(g["fastgelu"]))
+
+
+def test_activation_mul_clamp(port, golden_scalars):
+    g = golden_scalars
+    acc = g["amc_in"]
+    np.testing.assert_array_equal(np.array([port.act_mul_clamp(0.03, int(v)) for v in acc], np.int8), g["amc_0p03"])
+    np.testing.assert_array_equal(
+        np.array([port.act_mul_clamp_from_float(0.03, float(v)) for v in acc], np.int8), g["amc_from_float_0p03"])
+
+
+def test_multiply_multiply_and_mafg(port, golden_scalars):
+    g = golden_scalars
+    c, d0, d1 = g["mm_c"], g["mm_d0"], g["mm_d1"]
+    np.testing.assert_array_equal(
+        np.array([port.multiply_multiply_f16(float(a), float(b), float(e)) for a, b, e in zip(c, d0, d1)], np.uint16),
+        g["mm_f16"])
+    np.testing.assert_array_equal(
+        np.array([port.multiply_multiply_bf16(float(a), float(b), float(e)) for a, b, e in zip(c, d0, d1)], np.uint16),
+        g["mm_bf16"])
+    np.testing.assert_array_equal(
+        np.array([port.multiply_add_fastgelu_bf16(float(a), int(x), int(y))
+                  for a, x, y in zip(c, g["mafg_d0"], g["mafg_d1"])], np.uint16),
+        g["mafg_bf16"])
+
+
+def test_generators(port, golden_scalars):
+    g = golden_scalars
+    for dt in ("f16", "bf16", "i8", "f32"):
+        for iv in (0, 1):
+            got = port.fill_uniform(96, dt, -1.0, 1.0, bool(iv))
+            exp = g[f"fill_{dt}_{iv}"]
+            if dt == "f32":
+                np.testing.assert_array_equal(_bits(got), _bits(exp))
+            else:
+                np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(port.fill_uniform(96, "i8", -8.0, 7.0, True), g["fill_i8_int4range"])
+    np.testing.assert_array_equal(port.generator2_i8(8, 12, 12, 1, -128, 127, seed=1), g["gen2_i8_seed1"])
+    np.testing.assert_array_equal(port.generator2_i8(8, 12, 1, 8, -5, 5, seed=1), g["gen2_i8_seed1_col"])
+
+
+def test_fpaintb_cases(port, golden_gemm):
+    g = golden_gemm
+    for tag in ("fpaintb_real", "fpaintb_int", "fpaintb_ragged", "fpaintb_i8"):
+        M, N, K, lda, ldb, ldc = (int(v) for v in g[f"{tag}_shape"])
+        got = port.fpAintB_gemm_f16(g[f"{tag}_a"], g[f"{tag}_b"], g[f"{tag}_s"], M, N, K, lda, ldb, ldc)
+        np.testing.assert_array_equal(got, g[f"{tag}_c"], err_msg=tag)
+
+
+def test_example64_inputs_and_outputs(port, golden_gemm):
+    # example/64 fills A, quant-B and scale each from a fresh mt19937(11939)
+    for init in (1, 2):
+        M, N, K = 32, 32, 64
+        a = port.fill_uniform(M * K, "f16", -1.0, 1.0, init == 1).reshape(M, K)
+        b = port.fill_uniform(K * N, "i8", -1.0, 1.0, init == 1).reshape(N, K)
+        s = port.fill_uniform(N, "f16", -1.0, 1.0, init == 1)
+        got = port.fpAintB_gemm_f16(a, b, s, M, N, K, K, K, N)
+        np.testing.assert_array_equal(got, golden_gemm[f"ex64_init{init}_c"])
+
+
+def test_c1_int8_requant_256(port, golden_gemm):
+    """BASELINE config 1: int8 x int8 M=N=K=256 through the host ReferenceGemm of example/14."""
+    M = N = K = 256
+    a = port.generator2_i8(M, K, K, 1, -128, 127, seed=1)
+    b = port.generator2_i8(K, N, 1, K, -128, 127, seed=-1)
+    np.testing.assert_array_equal(a[:64], golden_gemm["c1_a_head"])
+    np.testing.assert_array_equal(b[:64], golden_gemm["c1_b_head"])
+    e = port.gemm_i8_requant(a, b, M, N, K, K, K, N, 0.03).reshape(M, N)
+    np.testing.assert_array_equal(e, golden_gemm["c1_e"])
+
+
+def test_i8_small_ragged(port, golden_gemm):
+    g = golden_gemm
+    e = port.gemm_i8_requant(g["i8_small_a"], g["i8_small_b"], 40, 24, 96, 104, 100, 32, 0.25)
+    np.testing.assert_array_equal(e, g["i8_small_e"])
+
+
+def test_bf16_i8_cases(port, golden_gemm):
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    a, s, bcol, d0, d1 = g["bf16_a"], g["bf16_s"], g["bf16_bcol"], g["bf16_d0"], g["bf16_d1"]
+    for ep in (0, 1, 2):
+        got = port.gemm_bf16_i8(a, bcol, s, M, N, K, K, 1, K, N, ep, d0, d1)
+        np.testing.assert_array_equal(got, g[f"bf16_e_col_ep{ep}"], err_msg=f"epilogue {ep}")
+    brow = np.ascontiguousarray(bcol.T)
+    got = port.gemm_bf16_i8(a, brow, s, M, N, K, K, N, 1, N, 1, d0, d1)
+    np.testing.assert_array_equal(got, g["bf16_e_row_ep1"])
+
+
+def test_f8_i4_multiply_multiply(port, golden_gemm):
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    for key, gelu in (("f8_e_mm", False), ("f8_e_mm_gelu", True)):
+        got = port.gemm_f8_i8_mm(g["f8_a"], g["f8_b"], g["f8_d0"], g["f8_d1"], M, N, K, K, K, N, gelu)
+        np.testing.assert_array_equal(got, g[key], err_msg=key)
+
+
+def test_pack_int4_roundtrip_and_layout(port):
+    rng = np.random.default_rng(1)
+    K, N = 64, 5
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    p = port.pack_int4(q, K, N)
+    assert p.shape == (N, K // 2)
+    np.testing.assert_array_equal(port.unpack_int4(p, K, N), q)
+    # layout: 32-bit word g of column n, nibble p<4 -> k=8g+2p, p>=4 -> k=8g+2(p-4)+1, value q+8
+    w = p.reshape(N, K // 8, 4).astype(np.uint32)
+    w = w[..., 0] | (w[..., 1] << 8) | (w[..., 2] << 16) | (w[..., 3] << 24)
+    for pos in range(8):
+        k_in = 2 * pos if pos < 4 else 2 * (pos - 4) + 1
+        nib = (w >> (4 * pos)) & 0xF
+        np.testing.assert_array_equal(nib.astype(np.int32) - 8, q.reshape(N, K // 8, 8)[..., k_in])
+    # every value of the int4 range round-trips (reference limits: test/data_type/test_int4.cpp:19-52)
+    allv = np.tile(np.arange(-8, 8, dtype=np.int8), 4).reshape(1, 64)
+    np.testing.assert_array_equal(port.unpack_int4(port.pack_int4(allv, 64, 1), 64, 1), allv)
+    # rejected: K not a multiple of 8, value out of range
+    import pytest
+    with pytest.raises(ValueError):
+        port.pack_int4(q[:, :60].copy(), 60, N)
+    bad = q.copy()
+    bad[0, 0] = 8
+    with pytest.raises(ValueError):
+        port.pack_int4(bad, K, N)
+
+
+def test_splitk_partition_and_reduce(port):
+    # KRead = ceil(K / (KBatch*v)) * v ; the last slice takes the remainder
+    assert port.splitk_kread(65536, 8, 64) == 8192
+    assert port.splitk_kread(437, 3, 8) == 152
+    assert port.splitk_kread(4096, 5, 64) == 832
+    rng = np.random.default_rng(3)
+    M, N, K, kb = 16, 24, 256, 3
+    a = np.round(rng.uniform(-2, 2, (M, K))).astype(np.float16).view(np.uint16)
+    b = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    s = rng.integers(1, 3, N).astype(np.float16).view(np.uint16)
+    kr = port.splitk_kread(K, kb, 64)
+    parts = np.stack([port.fpAintB_partial(a, b, s, M, N, K, K, z * kr, min(K, (z + 1) * kr)) for z in range(kb)])
+    full = port.fpAintB_gemm_f16(a, b, s, M, N, K, K, K, N)
+    # integer-valued inputs: partial sums are exact, so split-K equals the one-pass result bit for bit
+    np.testing.assert_array_equal(port.splitk_reduce_f16(parts), full)
