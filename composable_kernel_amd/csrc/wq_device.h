@@ -1,0 +1,280 @@
+// Device-side building blocks shared by the gfx950 weight-quantized GEMM kernels:
+// vector types, in-register dequantisation of B fragments, epilogue functors and stores.
+//
+// Numerics follow Composable Kernel's host reference (paths relative to its tree):
+//   fp16 dequant  half(q) * scale, rounded once to half   reference_fpAintB_gemm.hpp:110
+//   bf16 dequant  trunc_bf16(float(q) * float(scale))     binary_element_wise_operation.hpp:182-190
+//   float -> bf16 truncation                              include/ck/utility/type_convert.hpp:53-64
+//   float -> half round-to-nearest-even                   include/ck/utility/type_convert.hpp:17-25
+// This file must be compiled with -ffp-contract=off: the reference's epilogues are separate
+// multiplies and adds.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace wq {
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+
+enum AKind
+{
+    A_F16  = 0,
+    A_BF16 = 1
+};
+enum BKind
+{
+    B_I4P  = 0, // packed offset-binary int4, 8 k per 32-bit word
+    B_U8O  = 1, // uint8 = q + 128
+    B_I8   = 2  // signed int8
+};
+
+template <int BK>
+struct BInfo;
+template <>
+struct BInfo<B_I4P>
+{
+    static constexpr int kBytesPer8K = 4; // bytes holding 8 consecutive k of one column
+};
+template <>
+struct BInfo<B_U8O>
+{
+    static constexpr int kBytesPer8K = 8;
+};
+template <>
+struct BInfo<B_I8>
+{
+    static constexpr int kBytesPer8K = 8;
+};
+
+__device__ __forceinline__ h2_t as_h2(uint32_t u) { return __builtin_bit_cast(h2_t, u); }
+__device__ __forceinline__ uint32_t as_u32(h2_t h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return as_f32((uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_trunc(float f) { return (uint16_t)(as_u32(f) >> 16); }
+
+// ---------------------------------------------------------------------------------------------
+// Per-lane scale operand.  For fp16 activations it is {s,s} as a packed half pair; for bf16
+// activations it is s widened to fp32 plus the precomputed -128*s (exact: power-of-two multiple).
+// ---------------------------------------------------------------------------------------------
+template <int AK>
+struct ScaleReg;
+template <>
+struct ScaleReg<A_F16>
+{
+    h2_t s2;
+    __device__ __forceinline__ void set(uint16_t bits)
+    {
+        const uint32_t u = (uint32_t)bits | ((uint32_t)bits << 16);
+        s2               = as_h2(u);
+    }
+};
+template <>
+struct ScaleReg<A_BF16>
+{
+    float s, m128s;
+    __device__ __forceinline__ void set(uint16_t bits)
+    {
+        s     = bf16_to_f32(bits);
+        m128s = -128.0f * s;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Dequantise the 8 consecutive-k weights one lane feeds to one MFMA (k = 8g .. 8g+7 of one
+// column) into the 4 VGPRs of a 16-bit operand fragment, element j <-> k = 8g + j.
+// ---------------------------------------------------------------------------------------------
+
+// fp16 x packed int4.  0x6400 | n is the half 1024 + n, so (w & 0x000F000F) | 0x64006400 holds
+// the pair (1024 + nibble_i, 1024 + nibble_{i+4}); subtracting 1032 leaves q = n - 8 exactly.
+// Nibbles at bit 4 are kept in place, giving 1024 + 16 n, and (x * 1/16 - 72) = n - 8 exactly.
+// The multiply by the scale is then the single rounding the reference performs.
+__device__ __forceinline__ u4_t dequant8(const ScaleReg<A_F16>& sc, uint32_t w,
+                                         std::integral_constant<int, B_I4P>)
+{
+    const h2_t k1032 = {(_Float16)1032.0f, (_Float16)1032.0f};
+    const h2_t k16th = {(_Float16)0.0625f, (_Float16)0.0625f};
+    const h2_t km72  = {(_Float16)-72.0f, (_Float16)-72.0f};
+    const uint32_t w8 = w >> 8;
+    const h2_t t0     = as_h2((w & 0x000F000Fu) | 0x64006400u);
+    const h2_t t1     = as_h2((w & 0x00F000F0u) | 0x64006400u);
+    const h2_t t2     = as_h2((w8 & 0x000F000Fu) | 0x64006400u);
+    const h2_t t3     = as_h2((w8 & 0x00F000F0u) | 0x64006400u);
+    const h2_t q0     = t0 - k1032;
+    const h2_t q1     = __builtin_elementwise_fma(t1, k16th, km72);
+    const h2_t q2     = t2 - k1032;
+    const h2_t q3     = __builtin_elementwise_fma(t3, k16th, km72);
+    u4_t r;
+    r[0] = as_u32(q0 * sc.s2);
+    r[1] = as_u32(q1 * sc.s2);
+    r[2] = as_u32(q2 * sc.s2);
+    r[3] = as_u32(q3 * sc.s2);
+    return r;
+}
+
+// fp16 x 8-bit weights.  v_perm_b32 builds the half pair (0x64 b1, 0x64 b0) = (1024 + b1,
+// 1024 + b0); subtracting 1152 leaves b - 128 = q exactly (the u8 -> half conversion of
+// unary_element_wise_operation.hpp:1060-1091).  Signed bytes are first flipped to offset form.
+template <int BKIND>
+__device__ __forceinline__ u4_t dequant8_bytes_f16(const ScaleReg<A_F16>& sc, u2_t w)
+{
+    if constexpr(BKIND == B_I8)
+    {
+        w[0] ^= 0x80808080u;
+        w[1] ^= 0x80808080u;
+    }
+    const h2_t k1152 = {(_Float16)1152.0f, (_Float16)1152.0f};
+    const h2_t t0    = as_h2(__builtin_amdgcn_perm(0x64646464u, w[0], 0x04010400u));
+    const h2_t t1    = as_h2(__builtin_amdgcn_perm(0x64646464u, w[0], 0x04030402u));
+    const h2_t t2    = as_h2(__builtin_amdgcn_perm(0x64646464u, w[1], 0x04010400u));
+    const h2_t t3    = as_h2(__builtin_amdgcn_perm(0x64646464u, w[1], 0x04030402u));
+    u4_t r;
+    r[0] = as_u32((t0 - k1152) * sc.s2);
+    r[1] = as_u32((t1 - k1152) * sc.s2);
+    r[2] = as_u32((t2 - k1152) * sc.s2);
+    r[3] = as_u32((t3 - k1152) * sc.s2);
+    return r;
+}
+
+// bf16 x 8-bit weights.  float(q) * float(scale) has at most 16 significant bits, so it is exact
+// in fp32 and fma(float(q + 128), s, -128 s) returns exactly that product; the reference then
+// truncates to bf16, which is "keep the upper half-word" (v_perm_b32 packs two of them).
+__device__ __forceinline__ float u8_to_f32(uint32_t w, int byte)
+{
+    return (float)((w >> (8 * byte)) & 0xFFu); // v_cvt_f32_ubyteN
+}
+template <int BKIND>
+__device__ __forceinline__ u4_t dequant8_bytes_bf16(const ScaleReg<A_BF16>& sc, u2_t w)
+{
+    if constexpr(BKIND == B_I8)
+    {
+        w[0] ^= 0x80808080u;
+        w[1] ^= 0x80808080u;
+    }
+    u4_t r;
+#pragma unroll
+    for(int d = 0; d < 2; ++d)
+    {
+        const float p0 = __builtin_fmaf(u8_to_f32(w[d], 0), sc.s, sc.m128s);
+        const float p1 = __builtin_fmaf(u8_to_f32(w[d], 1), sc.s, sc.m128s);
+        const float p2 = __builtin_fmaf(u8_to_f32(w[d], 2), sc.s, sc.m128s);
+        const float p3 = __builtin_fmaf(u8_to_f32(w[d], 3), sc.s, sc.m128s);
+        r[2 * d]     = __builtin_amdgcn_perm(as_u32(p1), as_u32(p0), 0x07060302u);
+        r[2 * d + 1] = __builtin_amdgcn_perm(as_u32(p3), as_u32(p2), 0x07060302u);
+    }
+    return r;
+}
+
+// bf16 x packed int4: same exactness argument with float(n) * s - 8 s.
+__device__ __forceinline__ u4_t dequant8(const ScaleReg<A_BF16>& sc, uint32_t w,
+                                         std::integral_constant<int, B_I4P>)
+{
+    const float m8s = sc.m128s * 0.0625f; // -8 s, exact
+    u4_t r;
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+    {
+        const float lo = __builtin_fmaf((float)((w >> (4 * i)) & 0xFu), sc.s, m8s);
+        const float hi = __builtin_fmaf((float)((w >> (4 * i + 16)) & 0xFu), sc.s, m8s);
+        r[i]           = __builtin_amdgcn_perm(as_u32(hi), as_u32(lo), 0x07060302u);
+    }
+    return r;
+}
+
+// Scalar dequantisation of one weight (generic kernel); same arithmetic as above.
+template <int AK>
+__device__ __forceinline__ float dequant_scalar(int q, uint16_t scale_bits)
+{
+    if constexpr(AK == A_F16)
+    {
+        const _Float16 s = __builtin_bit_cast(_Float16, scale_bits);
+        const _Float16 v = (_Float16)(float)q * s; // one rounding to half
+        return (float)v;
+    }
+    else
+    {
+        const float p = (float)q * bf16_to_f32(scale_bits);
+        return as_f32(as_u32(p) & 0xFFFF0000u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogues.  x is the fp32 accumulator of output element (m, n).
+// ---------------------------------------------------------------------------------------------
+struct EpilogueArgs
+{
+    int kind;      // wq_epilogue
+    int c_dtype;   // wq_dtype of the output
+    float requant; // Activation_Mul_Clamp
+    const void* d0;
+    const void* d1;
+};
+
+// unary_element_wise_operation.hpp:443-452 (host form: true exp and true division, in fp32 here)
+__device__ __forceinline__ float fast_gelu(float x)
+{
+    const float c1  = (float)(-2.0 * 0.035677f);
+    const float c2  = (float)(-2.0 * 0.797885f);
+    const float u   = x * (c1 * x * x + c2);
+    const float emu = expf(u);
+    return x / (1.f + emu);
+}
+
+__device__ __forceinline__ float load_d_as_f32(const void* d, int idx, int c_dtype)
+{
+    // MultiplyAddFastGelu operands have the output's 16-bit type
+    const uint16_t bits = ((const uint16_t*)d)[idx];
+    if(c_dtype == 1 /*WQ_BF16*/)
+        return bf16_to_f32(bits);
+    return (float)__builtin_bit_cast(_Float16, bits);
+}
+
+__device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, int m, int n)
+{
+    switch(e.kind)
+    {
+    case 1: return fast_gelu(x);
+    case 2: {
+        // element_wise_operation.hpp:277-295: FastGelu(c * d0 + d1), separate multiply and add
+        const float t = x * load_d_as_f32(e.d0, n, e.c_dtype);
+        return fast_gelu(t + load_d_as_f32(e.d1, n, e.c_dtype));
+    }
+    case 3: {
+        // element_wise_operation.hpp:252-275: c * d0 * d1 left to right
+        const float t = x * ((const float*)e.d0)[n];
+        return t * ((const float*)e.d1)[m];
+    }
+    case 4: {
+        const float t = x * ((const float*)e.d0)[n];
+        return fast_gelu(t * ((const float*)e.d1)[m]);
+    }
+    default: return x;
+    }
+}
+
+// quantization_operation.hpp:39-45 on an int32 accumulator
+__device__ __forceinline__ int8_t act_mul_clamp(float requant, int acc)
+{
+    float y = requant * (float)acc;
+    y       = fminf(fmaxf(y, -128.f), 127.f);
+    return (int8_t)y; // toward zero
+}
+
+__device__ __forceinline__ uint16_t cvt_out16(float v, int c_dtype)
+{
+    if(c_dtype == 1 /*WQ_BF16*/)
+        return f32_to_bf16_trunc(v);
+    return __builtin_bit_cast(uint16_t, (_Float16)v);
+}
+
+} // namespace wq

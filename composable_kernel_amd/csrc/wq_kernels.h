@@ -1,0 +1,415 @@
+// gfx950 kernels of the weight-quantized GEMM engine.
+//
+//   wq_gemm_mfma_128      128x128x64 tile, 4 waves, LDS-DMA staging, in-register dequant,
+//                         v_mfma_f32_16x16x32_{f16,bf16}
+//   wq_gemm_generic       any shape / stride; one output element per thread (edge shapes, tests)
+//   wq_reduce_finalize    split-K: sum fp32 partials, epilogue, convert
+//   wq_pack_int4          int8-held int4 (K,N) column-major -> packed offset-binary nibbles
+//
+// Orientation of the MFMA: the WEIGHT fragment is the first operand (its 16 rows are 16 output
+// channels n) and the ACTIVATION fragment the second (its 16 columns are 16 rows m of C), so the
+// accumulator of lane l holds C[m = l & 15][n = 4 (l >> 4) + j], j = 0..3: four consecutive n of
+// one row of a row-major C, i.e. one 8-byte (16-bit C) or 16-byte (fp32 partial) store.
+#pragma once
+
+#include "wq_device.h"
+
+namespace wq {
+
+struct GemmParams
+{
+    const void* a;     // activations, row-major (M, lda)
+    const void* b;     // weights, K contiguous per column n
+    const void* scale; // N scales of A's 16-bit type
+    void* c;           // output, row-major (M, ldc); fp32 partial slabs when partial != 0
+    int M, N, K;
+    int lda;       // elements
+    int ldb_bytes; // bytes between consecutive columns of b
+    int ldc;       // elements
+    int k_begin;   // first k of this launch
+    int k_end;     // one past the last k of this launch
+    int k_per_z;   // K extent handled by one blockIdx.z (split-K inside the GPU)
+    int partial;   // 1: store raw fp32 accumulators to slab blockIdx.z of c (ld = ldc)
+    int tiles_m, tiles_n;
+    EpilogueArgs epi;
+};
+
+// XCD-aware block remap: blocks b and b + 8 share an XCD (and its L2) under round-robin
+// dispatch, so give each of the 8 groups a contiguous run of tile ids.  Bijective for any grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// Within the remapped order walk tiles in groups of 8 tile-rows so that concurrently resident
+// blocks share activation rows and weight columns in L2.
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn)
+{
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g         = t / per_group;
+    const int first_m   = g * GROUP;
+    const int gsz       = min(tiles_m - first_m, GROUP);
+    const int r         = t - g * per_group;
+    tm                  = first_m + r % gsz;
+    tn                  = r / gsz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128 x 128 x 64 MFMA kernel
+// ---------------------------------------------------------------------------------------------
+template <int AK, int BKIND>
+struct Mfma128
+{
+    static constexpr int BM = 128, BN = 128, BK = 64, THREADS = 256;
+    static constexpr int A_ROW_BYTES = BK * 2;                                // 128
+    static constexpr int B_ROW_BYTES = BK / 8 * BInfo<BKIND>::kBytesPer8K;    // 32 or 64
+    static constexpr int A_TILE      = BM * A_ROW_BYTES;                      // 16 KiB
+    static constexpr int B_TILE      = BN * B_ROW_BYTES;                      // 4 or 8 KiB
+    static constexpr int STAGE       = A_TILE + B_TILE;
+    static constexpr int LDS_BYTES   = 2 * STAGE;
+};
+
+// One 16-byte LDS-DMA per lane: LDS destination = wave-uniform base + 16 * lane.
+__device__ __forceinline__ void glds16(const void* gsrc, uint8_t* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0,
+                                     0);
+}
+
+template <int AK, int BKIND>
+__global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
+{
+    using T = Mfma128<AK, BKIND>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[T::LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr   = lane & 15; // index inside a 16-wide operand (row of the weight tile / column of the activation tile)
+    const int fq   = lane >> 4; // k group: k = 8 fq .. 8 fq + 7 inside a 32-deep MFMA step
+
+    int tm, tn;
+    {
+        const int nwg = p.tiles_m * p.tiles_n;
+        tile_coords(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, tm, tn);
+    }
+    const int m0 = tm * T::BM, n0 = tn * T::BN;
+    const int wm = wave & 1, wn = wave >> 1; // this wave's 64 x 64 quadrant of the block tile
+
+    const int kz_begin = p.k_begin + blockIdx.z * p.k_per_z;
+    const int kz_end   = min(p.k_end, kz_begin + p.k_per_z);
+    const int ntiles   = (kz_end - kz_begin) / T::BK;
+
+    // ---- per-lane scale registers, one per 16-column weight tile of this wave --------------
+    // One coalesced load of the wave's 64 scales, then a cross-lane broadcast: lane l needs the
+    // scale of column 16 nt + (l & 15).
+    ScaleReg<AK> sc[4];
+    {
+        const uint16_t mine = ((const uint16_t*)p.scale)[n0 + wn * 64 + lane];
+#pragma unroll
+        for(int nt = 0; nt < 4; ++nt)
+            sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));
+    }
+
+    // ---- staging addresses -------------------------------------------------------------------
+    // A tile: 128 rows x 128 B.  One wave-instruction moves 8 rows (lane -> row lane/8, 16-byte
+    // chunk lane%8); the chunk fetched is XOR-swizzled with (row & 7) so that the fragment reads
+    // below are bank-conflict free while the LDS image stays lane-linear.
+    const uint8_t* a_src[4];
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+    {
+        const int row   = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        a_src[i] = (const uint8_t*)p.a + ((size_t)(m0 + row) * p.lda + kz_begin) * 2 + chunk * 16;
+    }
+    // B tile: 128 columns x B_ROW_BYTES.
+    constexpr int B_CHUNKS = T::B_ROW_BYTES / 16;              // 16-byte chunks per column: 2 or 4
+    constexpr int B_COLS_PER_INSTR = 64 / B_CHUNKS;            // 32 or 16
+    constexpr int B_INSTR = T::BN / B_COLS_PER_INSTR / 4;      // per wave: 1 or 2
+    const uint8_t* b_src[B_INSTR];
+#pragma unroll
+    for(int i = 0; i < B_INSTR; ++i)
+    {
+        const int col   = (wave * B_INSTR + i) * B_COLS_PER_INSTR + lane / B_CHUNKS;
+        const int chunk = (lane % B_CHUNKS) ^ ((col >> 2) & (B_CHUNKS - 1));
+        b_src[i]        = (const uint8_t*)p.b + (size_t)(n0 + col) * p.ldb_bytes +
+                   (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + chunk * 16;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        uint8_t* sa = lds + buf * T::STAGE;
+        uint8_t* sb = sa + T::A_TILE;
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+            glds16(a_src[i] + (size_t)kt * T::A_ROW_BYTES, sa + (wave * 4 + i) * 1024);
+#pragma unroll
+        for(int i = 0; i < B_INSTR; ++i)
+            glds16(b_src[i] + (size_t)kt * T::B_ROW_BYTES, sb + (wave * B_INSTR + i) * 1024);
+    };
+
+    f4_t acc[4][4]; // [nt][mt]
+#pragma unroll
+    for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < 4; ++mt)
+            acc[nt][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const uint8_t* sa = lds + buf * T::STAGE;
+        const uint8_t* sb = sa + T::A_TILE;
+#pragma unroll
+        for(int s = 0; s < 2; ++s)
+        {
+            u4_t wf[4], af[4];
+#pragma unroll
+            for(int nt = 0; nt < 4; ++nt)
+            {
+                const int col = wn * 64 + nt * 16 + fr;
+                if constexpr(BKIND == B_I4P)
+                {
+                    const int chunk  = s ^ ((col >> 2) & 1);
+                    const uint32_t w = *(const uint32_t*)(sb + col * 32 + chunk * 16 + fq * 4);
+                    wf[nt]           = dequant8(sc[nt], w, std::integral_constant<int, B_I4P>{});
+                }
+                else
+                {
+                    const int chunk = (2 * s + (fq >> 1)) ^ ((col >> 2) & 3);
+                    const u2_t w    = *(const u2_t*)(sb + col * 64 + chunk * 16 + (fq & 1) * 8);
+                    if constexpr(AK == A_F16)
+                        wf[nt] = dequant8_bytes_f16<BKIND>(sc[nt], w);
+                    else
+                        wf[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], w);
+                }
+            }
+#pragma unroll
+            for(int mt = 0; mt < 4; ++mt)
+            {
+                const int row   = wm * 64 + mt * 16 + fr;
+                const int chunk = (4 * s + fq) ^ (row & 7);
+                af[mt]          = *(const u4_t*)(sa + row * 128 + chunk * 16);
+            }
+#pragma unroll
+            for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for(int mt = 0; mt < 4; ++mt)
+                {
+                    if constexpr(AK == A_F16)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            __builtin_bit_cast(h8_t, wf[nt]), __builtin_bit_cast(h8_t, af[mt]),
+                            acc[nt][mt], 0, 0, 0);
+                    else
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf8_t, wf[nt]), __builtin_bit_cast(bf8_t, af[mt]),
+                            acc[nt][mt], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop: prefetch tile t+1 by LDS-DMA while computing tile t ---------------------
+    if(ntiles > 0)
+    {
+        stage(0, 0);
+        __syncthreads(); // drains the DMA (vmcnt(0)) and publishes the tile
+        for(int t = 0; t < ntiles; ++t)
+        {
+            const int cur = t & 1;
+            if(t + 1 < ntiles)
+                stage(cur ^ 1, t + 1);
+            compute(cur);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+#pragma unroll
+    for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < 4; ++mt)
+        {
+            const int m = m0 + wm * 64 + mt * 16 + fr;
+            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+            if(p.partial)
+            {
+                float* dst = (float*)p.c + (size_t)blockIdx.z * p.M * p.ldc + (size_t)m * p.ldc + n;
+                *(f4_t*)dst = acc[nt][mt];
+            }
+            else
+            {
+                uint16_t o[4];
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+                    o[j] = cvt_out16(apply_epilogue(p.epi, acc[nt][mt][j], m, n + j), p.epi.c_dtype);
+                u2_t pk;
+                pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+                pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                *(u2_t*)((uint16_t*)p.c + (size_t)m * p.ldc + n) = pk;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel: any M, N, K slice and strides; one thread per output element, fp32 accumulate
+// in ascending k (the reference's own evaluation order).
+// ---------------------------------------------------------------------------------------------
+struct GenericParams
+{
+    const void* a;
+    const void* b;
+    const void* scale;
+    void* c;
+    int M, N, K;
+    long a_sm, a_sk; // element strides of A(m,k)
+    long b_sk, b_sn; // element strides of B(k,n); for packed int4: b_sn in BYTES, K contiguous
+    int ldc;
+    int k_begin, k_end, k_per_z, partial;
+    int a_dtype, b_dtype; // wq_dtype
+    EpilogueArgs epi;
+};
+
+__device__ __forceinline__ float f8_fnuz_to_f32(uint8_t x)
+{
+    // E4M3 FNUZ: bias 8, 0x80 = NaN, subnormals m * 2^-10 (f8_utils.hpp:186-267)
+    if(x == 0x80)
+        return __builtin_nanf("");
+    const int e   = (x >> 3) & 15;
+    const int m   = x & 7;
+    const float v = e == 0 ? (float)m * 0.0009765625f : __builtin_ldexpf((float)(8 + m), e - 11);
+    return (x & 0x80) ? -v : v;
+}
+
+__global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
+{
+    const int n = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int m = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if(m >= p.M || n >= p.N)
+        return;
+    const int kb = p.k_begin + blockIdx.z * p.k_per_z;
+    const int ke = min(p.k_end, kb + p.k_per_z);
+
+    if(p.a_dtype == 4 /*WQ_I8*/)
+    {
+        // int8 x int8 -> int32 (exact), then Activation_Mul_Clamp
+        int acc = 0;
+        for(int k = kb; k < ke; ++k)
+            acc += (int)((const int8_t*)p.a)[m * p.a_sm + k * p.a_sk] *
+                   (int)((const int8_t*)p.b)[k * p.b_sk + n * p.b_sn];
+        ((int8_t*)p.c)[(size_t)m * p.ldc + n] = act_mul_clamp(p.epi.requant, acc);
+        return;
+    }
+
+    const uint16_t sbits = p.scale ? ((const uint16_t*)p.scale)[n] : 0;
+    float acc            = 0.f;
+    for(int k = kb; k < ke; ++k)
+    {
+        int q;
+        if(p.b_dtype == 6 /*WQ_I4_PACKED*/)
+        {
+            const uint32_t w = *(const uint32_t*)((const uint8_t*)p.b + (size_t)n * p.b_sn + (k >> 3) * 4);
+            const int j      = k & 7;
+            const int pos    = (j & 1) ? 4 + (j >> 1) : (j >> 1);
+            q                = (int)((w >> (4 * pos)) & 0xFu) - 8;
+        }
+        else if(p.b_dtype == 5 /*WQ_U8_OFFSET*/)
+            q = (int)((const uint8_t*)p.b)[k * p.b_sk + n * p.b_sn] - 128;
+        else
+            q = (int)((const int8_t*)p.b)[k * p.b_sk + n * p.b_sn];
+
+        float va, vb;
+        if(p.a_dtype == 0 /*WQ_F16*/)
+        {
+            va = (float)((const _Float16*)p.a)[m * p.a_sm + k * p.a_sk];
+            vb = dequant_scalar<A_F16>(q, sbits);
+        }
+        else if(p.a_dtype == 1 /*WQ_BF16*/)
+        {
+            va = bf16_to_f32(((const uint16_t*)p.a)[m * p.a_sm + k * p.a_sk]);
+            vb = dequant_scalar<A_BF16>(q, sbits);
+        }
+        else /* WQ_F8_FNUZ: scales live in the epilogue */
+        {
+            va = f8_fnuz_to_f32(((const uint8_t*)p.a)[m * p.a_sm + k * p.a_sk]);
+            vb = (float)q;
+        }
+        acc += va * vb;
+    }
+    if(p.partial)
+        ((float*)p.c)[(size_t)blockIdx.z * p.M * p.ldc + (size_t)m * p.ldc + n] = acc;
+    else
+        ((uint16_t*)p.c)[(size_t)m * p.ldc + n] =
+            cvt_out16(apply_epilogue(p.epi, acc, m, n), p.epi.c_dtype);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-K reduce + epilogue: out(m,n) = cvt(epilogue(sum_z partial[z][m][n])), z ascending.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wq_reduce_finalize(const float* __restrict__ partials,
+                                                          int k_batch, int M, int N, int ld_part,
+                                                          void* c, int ldc, EpilogueArgs epi)
+{
+    const int n4    = N >> 2; // N % 4 == 0 is checked on the host
+    const long total = (long)M * n4;
+    for(long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+        i += (long)gridDim.x * blockDim.x)
+    {
+        const int m = (int)(i / n4);
+        const int n = (int)(i % n4) * 4;
+        f4_t s      = *(const f4_t*)(partials + (size_t)m * ld_part + n);
+        for(int z = 1; z < k_batch; ++z)
+        {
+            const f4_t v = *(const f4_t*)(partials + ((size_t)z * M + m) * ld_part + n);
+            s[0] += v[0];
+            s[1] += v[1];
+            s[2] += v[2];
+            s[3] += v[3];
+        }
+        if(epi.c_dtype == 3 /*WQ_F32*/)
+        {
+            f4_t o;
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                o[j] = apply_epilogue(epi, s[j], m, n + j);
+            *(f4_t*)((float*)c + (size_t)m * ldc + n) = o;
+        }
+        else
+        {
+            uint16_t o[4];
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                o[j] = cvt_out16(apply_epilogue(epi, s[j], m, n + j), epi.c_dtype);
+            u2_t pk;
+            pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+            pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+            *(u2_t*)((uint16_t*)c + (size_t)m * ldc + n) = pk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// int4 packer: one thread per 32-bit word (8 consecutive k of one column).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wq_pack_int4(const int8_t* __restrict__ q, int ldq, int K,
+                                                    int N, uint8_t* __restrict__ out, int ld_bytes)
+{
+    const int words = K >> 3;
+    const long total = (long)N * words;
+    for(long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+        i += (long)gridDim.x * blockDim.x)
+    {
+        const int n = (int)(i / words), g = (int)(i % words);
+        const int8_t* src = q + (size_t)n * ldq + 8 * g;
+        uint32_t w        = 0;
+#pragma unroll
+        for(int pos = 0; pos < 8; ++pos)
+        {
+            const int k = pos < 4 ? 2 * pos : 2 * (pos - 4) + 1;
+            w |= (uint32_t)((src[k] + 8) & 0xF) << (4 * pos);
+        }
+        *(uint32_t*)(out + (size_t)n * ld_bytes + 4 * g) = w;
+    }
+}
+
+} // namespace wq

@@ -1,0 +1,467 @@
+// C ABI of the gfx950 weight-quantized GEMM engine (declared in include/wqgemm.h): problem
+// validation, kernel selection, launches and timing.  No allocation and no synchronisation on the
+// launch path; errors are reported by status code plus a thread-local message.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "wqgemm.h"
+#include "wq_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define WQ_HIP(expr)                                                                         \
+    do                                                                                       \
+    {                                                                                        \
+        hipError_t e_ = (expr);                                                              \
+        if(e_ != hipSuccess)                                                                 \
+            return fail(WQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
+    } while(0)
+
+enum Route
+{
+    ROUTE_NONE = 0,
+    ROUTE_MFMA128,
+    ROUTE_GENERIC
+};
+
+struct Plan
+{
+    Route route   = ROUTE_NONE;
+    int ak        = 0; // wq::AKind
+    int bk        = 0; // wq::BKind
+    int k_begin   = 0;
+    int k_end     = 0;
+    int k_batch   = 1;
+    int k_per_z   = 0;
+    bool partial  = false; // main kernel writes fp32 partial slabs
+    bool to_c     = false; // ... directly into p->c (multi-GPU slice) instead of the workspace
+};
+
+bool is16(int dt) { return dt == WQ_F16 || dt == WQ_BF16; }
+
+// Validate and choose a kernel.  Returns WQ_OK and fills plan, or an error status with message.
+int make_plan(const wqgemm_problem* p, Plan& plan)
+{
+    if(!p)
+        return fail(WQ_ERR_INVALID, "null problem");
+    if(p->M <= 0 || p->N <= 0 || p->K <= 0)
+        return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
+    if(!p->a || !p->b || !p->c)
+        return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
+    if(p->flags != 0)
+        return fail(WQ_ERR_INVALID, "flags must be 0");
+    if(p->c_layout != WQ_ROW_MAJOR)
+        return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
+    if(p->a_layout != WQ_ROW_MAJOR && p->a_layout != WQ_COL_MAJOR)
+        return fail(WQ_ERR_INVALID, "bad a_layout");
+    if(p->b_layout != WQ_ROW_MAJOR && p->b_layout != WQ_COL_MAJOR)
+        return fail(WQ_ERR_INVALID, "bad b_layout");
+    if(p->lda < (p->a_layout == WQ_ROW_MAJOR ? p->K : p->M))
+        return fail(WQ_ERR_INVALID, "lda too small");
+    if(p->ldb < (p->b_layout == WQ_COL_MAJOR ? p->K : p->N))
+        return fail(WQ_ERR_INVALID, "ldb too small");
+    if(p->ldc < p->N)
+        return fail(WQ_ERR_INVALID, "ldc too small");
+    const int kb = p->k_batch <= 0 ? 1 : p->k_batch;
+    plan.k_batch = kb;
+    const bool slice = p->k_end > p->k_begin;
+    if(!slice && (p->k_begin != 0 || p->k_end != 0))
+        return fail(WQ_ERR_INVALID, "k_begin/k_end must both be 0 or satisfy k_end > k_begin");
+    plan.k_begin = slice ? p->k_begin : 0;
+    plan.k_end   = slice ? p->k_end : p->K;
+    if(plan.k_begin < 0 || plan.k_end > p->K)
+        return fail(WQ_ERR_INVALID, "K slice [%d,%d) outside [0,%d)", plan.k_begin, plan.k_end, p->K);
+    if(slice && kb != 1)
+        return fail(WQ_ERR_UNSUPPORTED, "k_batch > 1 cannot be combined with a K slice");
+    if(slice && p->c_dtype != WQ_F32)
+        return fail(WQ_ERR_INVALID, "a K-slice launch stores fp32 partials: c_dtype must be WQ_F32");
+    plan.partial = slice || kb > 1;
+    plan.to_c    = slice;
+    const int klen = plan.k_end - plan.k_begin;
+    plan.k_per_z   = kb > 1 ? wqgemm_splitk_kread(klen, kb, 64) : klen;
+    if(kb > 1 && (long)(kb - 1) * plan.k_per_z >= klen)
+        return fail(WQ_ERR_UNSUPPORTED, "k_batch %d leaves an empty K slice for K = %d", kb, klen);
+    if(plan.partial && (p->N % 4 != 0 || p->ldc % 4 != 0))
+        return fail(WQ_ERR_UNSUPPORTED, "split-K needs N and ldc to be multiples of 4");
+
+    // ---- int8 x int8 requantised GEMM (example/14, client_example/09) ------------------------
+    if(p->a_dtype == WQ_I8)
+    {
+        if(p->b_dtype != WQ_I8 || p->c_dtype != WQ_I8 || p->epilogue != WQ_EPI_ACT_MUL_CLAMP)
+            return fail(WQ_ERR_UNSUPPORTED, "int8 A needs int8 B, int8 C and Activation_Mul_Clamp");
+        if(plan.partial)
+            return fail(WQ_ERR_UNSUPPORTED, "split-K is not implemented for the int8 requant GEMM");
+        plan.route = ROUTE_GENERIC;
+        return WQ_OK;
+    }
+
+    // ---- fpAintB family ------------------------------------------------------------------------
+    if(p->a_dtype != WQ_F16 && p->a_dtype != WQ_BF16 && p->a_dtype != WQ_F8_FNUZ)
+        return fail(WQ_ERR_UNSUPPORTED, "unsupported A dtype %d", p->a_dtype);
+    if(p->b_dtype != WQ_I4_PACKED && p->b_dtype != WQ_U8_OFFSET && p->b_dtype != WQ_I8)
+        return fail(WQ_ERR_UNSUPPORTED, "unsupported B dtype %d", p->b_dtype);
+    if(p->b_dtype == WQ_I4_PACKED && (p->b_layout != WQ_COL_MAJOR || p->K % 8 != 0 || p->ldb % 8 != 0))
+        return fail(WQ_ERR_UNSUPPORTED,
+                    "packed int4 B must be column-major (K contiguous) with K and ldb multiples of 8");
+    if(p->b_dtype == WQ_I4_PACKED && (plan.k_begin % 8 != 0 || plan.k_per_z % 8 != 0))
+        return fail(WQ_ERR_UNSUPPORTED, "packed int4 K slices must start on multiples of 8");
+    if(is16(p->a_dtype))
+    {
+        if(!p->scale)
+            return fail(WQ_ERR_INVALID, "scale must be non-null for 16-bit activations");
+        if(p->scale_dtype != p->a_dtype)
+            return fail(WQ_ERR_UNSUPPORTED, "scale dtype must equal the activation dtype");
+    }
+    if(!slice)
+    {
+        // (a K-slice launch stores fp32 partials; its epilogue runs in wqgemm_reduce_finalize)
+        if(!is16(p->c_dtype))
+            return fail(WQ_ERR_UNSUPPORTED, "C must be fp16 or bf16");
+        if(is16(p->a_dtype) && p->c_dtype != p->a_dtype)
+            return fail(WQ_ERR_UNSUPPORTED, "C dtype must equal the activation dtype");
+    }
+    switch(p->epilogue)
+    {
+    case WQ_EPI_PASSTHROUGH:
+    case WQ_EPI_FASTGELU: break;
+    case WQ_EPI_MULTIPLY_ADD_FASTGELU:
+    case WQ_EPI_MULTIPLY_MULTIPLY:
+    case WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU:
+        if(!p->d0 || !p->d1)
+            return fail(WQ_ERR_INVALID, "epilogue %d needs d0 and d1", p->epilogue);
+        break;
+    default: return fail(WQ_ERR_UNSUPPORTED, "epilogue %d is not valid for this dtype", p->epilogue);
+    }
+
+    plan.ak = p->a_dtype == WQ_BF16 ? wq::A_BF16 : wq::A_F16;
+    plan.bk = p->b_dtype == WQ_I4_PACKED ? wq::B_I4P : (p->b_dtype == WQ_U8_OFFSET ? wq::B_U8O : wq::B_I8);
+
+    // The tiled MFMA kernel needs whole tiles, K-contiguous operands and 16-byte aligned rows;
+    // everything else goes to the generic kernel.
+    const int b_row_align = p->b_dtype == WQ_I4_PACKED ? 32 : 16; // ldb elements per 16 bytes
+    const bool tiled = is16(p->a_dtype) && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
+                       p->M % 128 == 0 && p->N % 128 == 0 && plan.k_begin % 64 == 0 &&
+                       plan.k_per_z % 64 == 0 && (plan.k_end - plan.k_begin) % 64 == 0 &&
+                       p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
+                       ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
+                       ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
+    plan.route = tiled ? ROUTE_MFMA128 : ROUTE_GENERIC;
+    return WQ_OK;
+}
+
+wq::EpilogueArgs epilogue_of(const wqgemm_problem* p)
+{
+    wq::EpilogueArgs e;
+    e.kind    = p->epilogue;
+    e.c_dtype = p->c_dtype;
+    e.requant = p->requant_scale;
+    e.d0      = p->d0;
+    e.d1      = p->d1;
+    return e;
+}
+
+template <int AK, int BKIND>
+void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
+}
+
+int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipStream_t s)
+{
+    void* out  = plan.partial && !plan.to_c ? workspace : p->c;
+    const int ld_out = plan.partial && !plan.to_c ? p->N : p->ldc;
+    if(plan.route == ROUTE_MFMA128)
+    {
+        wq::GemmParams gp;
+        gp.a         = p->a;
+        gp.b         = p->b;
+        gp.scale     = p->scale;
+        gp.c         = out;
+        gp.M         = p->M;
+        gp.N         = p->N;
+        gp.K         = p->K;
+        gp.lda       = p->lda;
+        gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb;
+        gp.ldc       = ld_out;
+        gp.k_begin   = plan.k_begin;
+        gp.k_end     = plan.k_end;
+        gp.k_per_z   = plan.k_per_z;
+        gp.partial   = plan.partial ? 1 : 0;
+        gp.tiles_m   = p->M / 128;
+        gp.tiles_n   = p->N / 128;
+        gp.epi       = epilogue_of(p);
+        const dim3 grid(gp.tiles_m * gp.tiles_n, 1, plan.k_batch);
+        if(plan.ak == wq::A_F16)
+        {
+            if(plan.bk == wq::B_I4P)
+                launch_mfma128<wq::A_F16, wq::B_I4P>(gp, grid, s);
+            else if(plan.bk == wq::B_U8O)
+                launch_mfma128<wq::A_F16, wq::B_U8O>(gp, grid, s);
+            else
+                launch_mfma128<wq::A_F16, wq::B_I8>(gp, grid, s);
+        }
+        else
+        {
+            if(plan.bk == wq::B_I4P)
+                launch_mfma128<wq::A_BF16, wq::B_I4P>(gp, grid, s);
+            else if(plan.bk == wq::B_U8O)
+                launch_mfma128<wq::A_BF16, wq::B_U8O>(gp, grid, s);
+            else
+                launch_mfma128<wq::A_BF16, wq::B_I8>(gp, grid, s);
+        }
+    }
+    else
+    {
+        wq::GenericParams gp;
+        gp.a     = p->a;
+        gp.b     = p->b;
+        gp.scale = p->scale;
+        gp.c     = out;
+        gp.M     = p->M;
+        gp.N     = p->N;
+        gp.K     = p->K;
+        gp.a_sm  = p->a_layout == WQ_ROW_MAJOR ? p->lda : 1;
+        gp.a_sk  = p->a_layout == WQ_ROW_MAJOR ? 1 : p->lda;
+        if(p->b_dtype == WQ_I4_PACKED)
+        {
+            gp.b_sk = 0;
+            gp.b_sn = p->ldb / 2;
+        }
+        else
+        {
+            gp.b_sk = p->b_layout == WQ_COL_MAJOR ? 1 : p->ldb;
+            gp.b_sn = p->b_layout == WQ_COL_MAJOR ? p->ldb : 1;
+        }
+        gp.ldc     = ld_out;
+        gp.k_begin = plan.k_begin;
+        gp.k_end   = plan.k_end;
+        gp.k_per_z = plan.k_per_z;
+        gp.partial = plan.partial ? 1 : 0;
+        gp.a_dtype = p->a_dtype;
+        gp.b_dtype = p->b_dtype;
+        gp.epi     = epilogue_of(p);
+        const dim3 grid((p->N + 15) / 16, (p->M + 15) / 16, plan.k_batch);
+        hipLaunchKernelGGL(wq::wq_gemm_generic, grid, dim3(256), 0, s, gp);
+    }
+    WQ_HIP(hipGetLastError());
+    return WQ_OK;
+}
+
+int launch_reduce(const wqgemm_problem* p, const float* partials, int k_batch, hipStream_t s)
+{
+    const long work = (long)p->M * (p->N / 4);
+    int blocks      = (int)((work + 255) / 256);
+    if(blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(wq::wq_reduce_finalize, dim3(blocks), dim3(256), 0, s, partials, k_batch,
+                       p->M, p->N, p->N, p->c, p->ldc, epilogue_of(p));
+    WQ_HIP(hipGetLastError());
+    return WQ_OK;
+}
+
+const char* dt_name(int dt)
+{
+    switch(dt)
+    {
+    case WQ_F16: return "F16";
+    case WQ_BF16: return "BF16";
+    case WQ_F8_FNUZ: return "F8";
+    case WQ_F32: return "F32";
+    case WQ_I8: return "I8";
+    case WQ_U8_OFFSET: return "U8";
+    case WQ_I4_PACKED: return "I4";
+    case WQ_I32: return "I32";
+    default: return "?";
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* wqgemm_version(void) { return "wqgemm 0.1 (gfx950)"; }
+
+const char* wqgemm_last_error(void) { return g_err; }
+
+int32_t wqgemm_splitk_kread(int32_t K, int32_t k_batch, int32_t granule)
+{
+    if(k_batch < 1)
+        k_batch = 1;
+    if(granule < 1)
+        granule = 1;
+    const long per = (long)k_batch * granule;
+    return (int32_t)(((long)K + per - 1) / per * granule);
+}
+
+int wqgemm_is_supported(const wqgemm_problem* p)
+{
+    Plan plan;
+    return make_plan(p, plan) == WQ_OK ? 1 : 0;
+}
+
+size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
+{
+    Plan plan;
+    if(make_plan(p, plan) != WQ_OK)
+        return 0;
+    if(plan.partial && !plan.to_c)
+        return (size_t)plan.k_batch * p->M * p->N * sizeof(float);
+    return 0;
+}
+
+int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
+{
+    Plan plan;
+    const int rc = make_plan(p, plan);
+    if(rc != WQ_OK)
+        return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if(plan.partial && !plan.to_c && !workspace)
+        return fail(WQ_ERR_WORKSPACE, "k_batch = %d needs a workspace of %zu bytes", plan.k_batch,
+                    (size_t)plan.k_batch * p->M * p->N * sizeof(float));
+    const int rm = launch_main(p, plan, workspace, s);
+    if(rm != WQ_OK)
+        return rm;
+    if(plan.partial && !plan.to_c)
+        return launch_reduce(p, (const float*)workspace, plan.k_batch, s);
+    return WQ_OK;
+}
+
+int wqgemm_run_timed(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters,
+                     int nrepeat, float* avg_ms)
+{
+    if(!avg_ms || nrepeat <= 0)
+        return fail(WQ_ERR_INVALID, "avg_ms must be non-null and nrepeat positive");
+    hipStream_t s = (hipStream_t)stream;
+    for(int i = 0; i < cold_iters; ++i)
+    {
+        const int rc = wqgemm_launch(p, workspace, stream);
+        if(rc != WQ_OK)
+            return rc;
+    }
+    hipEvent_t e0, e1;
+    WQ_HIP(hipEventCreate(&e0));
+    WQ_HIP(hipEventCreate(&e1));
+    WQ_HIP(hipEventRecord(e0, s));
+    for(int i = 0; i < nrepeat; ++i)
+    {
+        const int rc = wqgemm_launch(p, workspace, stream);
+        if(rc != WQ_OK)
+        {
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return rc;
+        }
+    }
+    WQ_HIP(hipEventRecord(e1, s));
+    WQ_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    WQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    WQ_HIP(hipEventDestroy(e0));
+    WQ_HIP(hipEventDestroy(e1));
+    *avg_ms = ms / (float)nrepeat;
+    return WQ_OK;
+}
+
+int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
+{
+    if(!buf || n == 0)
+        return fail(WQ_ERR_INVALID, "null buffer");
+    Plan plan;
+    if(make_plan(p, plan) != WQ_OK)
+    {
+        snprintf(buf, n, "DeviceWqGemm_gfx950<unsupported>");
+        return WQ_ERR_UNSUPPORTED;
+    }
+    if(plan.route == ROUTE_MFMA128)
+        snprintf(buf, n,
+                 "DeviceFpAintBGemm_Mfma_gfx950<256, 128, 128, 64, 16x16x32, %s, %s, %s, LdsDma, "
+                 "DequantInRegister, KBatch%d>",
+                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
+    else
+        snprintf(buf, n, "DeviceWqGemm_Generic_gfx950<256, 16, 16, %s, %s, %s, KBatch%d>",
+                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
+    return WQ_OK;
+}
+
+int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
+{
+    if(!buf || n == 0)
+        return fail(WQ_ERR_INVALID, "null buffer");
+    Plan plan;
+    const int rc = make_plan(p, plan);
+    if(rc != WQ_OK)
+        return rc;
+    snprintf(buf, n, "%s", plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128" : "wq_gemm_generic");
+    return WQ_OK;
+}
+
+int wqgemm_pack_int4(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t* out,
+                     int32_t ld_bytes, void* stream)
+{
+    if(!q || !out)
+        return fail(WQ_ERR_INVALID, "null pointer");
+    if(K <= 0 || N <= 0 || K % 8 != 0 || ldq < K || ld_bytes < K / 2 || ld_bytes % 4 != 0)
+        return fail(WQ_ERR_INVALID, "pack_int4: need K %% 8 == 0, ldq >= K, ld_bytes >= K/2, ld_bytes %% 4 == 0");
+    const long work = (long)N * (K / 8);
+    int blocks      = (int)((work + 255) / 256);
+    if(blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(wq::wq_pack_int4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q, ldq, K,
+                       N, out, ld_bytes);
+    WQ_HIP(hipGetLastError());
+    return WQ_OK;
+}
+
+int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t* out,
+                          int32_t ld_bytes)
+{
+    if(!q || !out)
+        return fail(WQ_ERR_INVALID, "null pointer");
+    if(K <= 0 || N <= 0 || K % 8 != 0 || ldq < K || ld_bytes < K / 2)
+        return fail(WQ_ERR_INVALID, "pack_int4_host: need K %% 8 == 0, ldq >= K, ld_bytes >= K/2");
+    for(int n = 0; n < N; ++n)
+        for(int g = 0; g < K / 8; ++g)
+        {
+            uint32_t w = 0;
+            for(int pos = 0; pos < 8; ++pos)
+            {
+                const int k = 8 * g + (pos < 4 ? 2 * pos : 2 * (pos - 4) + 1);
+                const int v = q[(size_t)n * ldq + k];
+                if(v < -8 || v > 7)
+                    return fail(WQ_ERR_INVALID, "pack_int4_host: value %d at (k=%d, n=%d) outside -8..7", v, k, n);
+                w |= (uint32_t)(v + 8) << (4 * pos);
+            }
+            memcpy(out + (size_t)n * ld_bytes + 4 * g, &w, 4);
+        }
+    return WQ_OK;
+}
+
+int wqgemm_reduce_finalize(const wqgemm_problem* p, const float* partials, int32_t k_batch,
+                           void* stream)
+{
+    if(!p || !partials || !p->c)
+        return fail(WQ_ERR_INVALID, "null pointer");
+    if(k_batch < 1 || p->M <= 0 || p->N <= 0 || p->N % 4 != 0 || p->ldc % 4 != 0 || p->ldc < p->N)
+        return fail(WQ_ERR_INVALID, "reduce_finalize: need k_batch >= 1, N %% 4 == 0, ldc %% 4 == 0");
+    if(p->c_dtype != WQ_F16 && p->c_dtype != WQ_BF16 && p->c_dtype != WQ_F32)
+        return fail(WQ_ERR_UNSUPPORTED, "reduce_finalize: C must be fp16, bf16 or fp32");
+    return launch_reduce(p, partials, k_batch, (hipStream_t)stream);
+}
+
+} // extern "C"

@@ -1,0 +1,159 @@
+/*
+ * wqgemm -- C ABI of the MI355X (gfx950) weight-quantized GEMM engine.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  The C++
+ * facade under include/ck/ (the DeviceGemm_dequantB / DeviceGemmMultipleD / ... interfaces of
+ * Composable Kernel) and the Python ctypes binding both sit on these entry points.  Every device
+ * pointer is a raw, non-owning HIP device pointer; every call is asynchronous on the given
+ * stream unless stated otherwise; no entry point throws -- status codes only.
+ *
+ * Reference paths below are relative to the Composable Kernel tree.
+ */
+#ifndef WQGEMM_H
+#define WQGEMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum wq_status
+{
+    WQ_OK              = 0,
+    WQ_ERR_UNSUPPORTED = 1, /* valid problem the engine has no kernel for (IsSupportedArgument == false) */
+    WQ_ERR_INVALID     = 2, /* malformed problem (null pointer, bad stride, bad enum)                     */
+    WQ_ERR_HIP         = 3, /* a HIP runtime call failed; see wqgemm_last_error()                         */
+    WQ_ERR_WORKSPACE   = 4  /* split-K requested without a workspace                                      */
+} wq_status;
+
+typedef enum wq_dtype
+{
+    WQ_F16       = 0, /* IEEE binary16                                                             */
+    WQ_BF16      = 1, /* bfloat16; float -> bf16 is TRUNCATION (include/ck/utility/type_convert.hpp:53-64) */
+    WQ_F8_FNUZ   = 2, /* E4M3 FNUZ bytes, bias 8, 0x80 = NaN (include/ck/utility/f8_utils.hpp:186-267)    */
+    WQ_F32       = 3,
+    WQ_I8        = 4, /* signed int8, one byte per element                                           */
+    WQ_U8_OFFSET = 5, /* uint8 = int8 + 128 (example/64_fpAintB_gemm/common.hpp:51-83)               */
+    WQ_I4_PACKED = 6, /* two offset-binary nibbles per byte, layout documented at wqgemm_pack_int4   */
+    WQ_I32       = 7
+} wq_dtype;
+
+typedef enum wq_layout
+{
+    WQ_ROW_MAJOR = 0, /* tensor_layout::gemm::RowMajor    (include/ck/tensor_operation/gpu/device/tensor_layout.hpp:13-24) */
+    WQ_COL_MAJOR = 1  /* tensor_layout::gemm::ColumnMajor */
+} wq_layout;
+
+/* Epilogue functors (include/ck/tensor_operation/gpu/element/...) applied to the fp32/int32
+ * accumulator before the store. */
+typedef enum wq_epilogue
+{
+    WQ_EPI_PASSTHROUGH                = 0, /* unary_element_wise_operation.hpp:28-225           */
+    WQ_EPI_FASTGELU                   = 1, /* unary_element_wise_operation.hpp:435-546          */
+    WQ_EPI_MULTIPLY_ADD_FASTGELU      = 2, /* element_wise_operation.hpp:277-295; d0[n], d1[n] of C's type */
+    WQ_EPI_MULTIPLY_MULTIPLY          = 3, /* element_wise_operation.hpp:252-275; d0[n], d1[m] float       */
+    WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU = 4, /* FastGelu(c*d0[n]*d1[m]); d0, d1 float                        */
+    WQ_EPI_ACT_MUL_CLAMP              = 5  /* quantization_operation.hpp:24-66; requant_scale, int8 out    */
+} wq_epilogue;
+
+/* One GEMM problem: C[M,N] = epilogue( sum_k A[m,k] * dequant(B[k,n], scale[n]) ).
+ * Mirrors what Argument objects capture in the reference
+ * (include/ck/tensor_operation/gpu/device/impl/device_fpAintB_gemm_wmma.hpp:343-417):
+ * raw pointers, sizes, strides in ELEMENTS of the named layout, functor state.
+ * B strides count logical elements; a packed-int4 column therefore occupies ldb/2 bytes. */
+typedef struct wqgemm_problem
+{
+    int32_t a_dtype, b_dtype, scale_dtype, c_dtype; /* wq_dtype                        */
+    int32_t a_layout, b_layout, c_layout;           /* wq_layout                       */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    const void* a;
+    const void* b;
+    const void* scale; /* N values of scale_dtype (lengths (K,N), strides (0,1)); NULL when the epilogue carries the scales */
+    void* c;
+    int32_t epilogue; /* wq_epilogue */
+    float requant_scale;
+    const void* d0;
+    const void* d1;
+    /* Split-K.  k_batch > 1 splits K inside one GPU: slice z reads [z*KRead, min(K,(z+1)*KRead)),
+     * KRead = ceil(K/(k_batch*64))*64 (gridwise_gemm_xdl_cshuffle_v3.hpp:192-197,583-590), fp32
+     * partials go to the caller's workspace and a reduce kernel applies the epilogue
+     * (device_gemm_xdl_cshuffle_v3r1.hpp:209-270).
+     * k_begin/k_end (k_end > k_begin) restrict the whole call to one K slice and make it store
+     * the raw fp32 partial to c (c_dtype must be WQ_F32, ldc in floats): the per-GPU step of
+     * multi-GPU split-K.  Both zero = the whole K range. */
+    int32_t k_batch;
+    int32_t k_begin, k_end;
+    int32_t flags; /* reserved, must be 0 */
+} wqgemm_problem;
+
+/* Library version string, e.g. "wqgemm 0.1 (gfx950)". */
+const char* wqgemm_version(void);
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char* wqgemm_last_error(void);
+
+/* 1 if wqgemm_launch can run the problem, else 0.
+ * Replaces BaseOperator::IsSupportedArgument
+ * (include/ck/tensor_operation/gpu/device/device_base.hpp:46;
+ *  impl/device_fpAintB_gemm_wmma.hpp:510-597). */
+int wqgemm_is_supported(const wqgemm_problem* p);
+
+/* Bytes of device workspace wqgemm_launch needs: k_batch*M*N*4 when k_batch > 1, else 0.
+ * Replaces BaseOperator::GetWorkSpaceSize
+ * (device_base.hpp:60; impl/device_gemm_xdl_cshuffle_v3r1.hpp:686-694). */
+size_t wqgemm_workspace_bytes(const wqgemm_problem* p);
+
+/* Enqueue the GEMM on `stream` (a hipStream_t; NULL = default stream).  Asynchronous, no
+ * synchronisation, no allocation.  Replaces Invoker::Run with time_kernel == false
+ * (impl/device_fpAintB_gemm_wmma.hpp:424-493; include/ck/host_utility/kernel_launch.hpp:71-77). */
+int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream);
+
+/* cold_iters untimed launches, then nrepeat launches between one pair of HIP events on
+ * `stream`; *avg_ms receives the mean.  Synchronises the stream.  Replaces Invoker::Run with
+ * time_kernel == true (include/ck/host_utility/kernel_launch.hpp:20-70;
+ * StreamConfig defaults cold 5 / repeat 50: include/ck/stream_config.hpp:9-19). */
+int wqgemm_run_timed(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters,
+                     int nrepeat, float* avg_ms);
+
+/* Instance name, written to buf (NUL-terminated, truncated to n).  Replaces
+ * BaseOperator::GetTypeString (device_base.hpp:47; impl/device_fpAintB_gemm_wmma.hpp:662-706). */
+int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n);
+
+/* Name of the __global__ function wqgemm_launch dispatches the main GEMM to (as it appears in
+ * rocprofv3 kernel traces).  No counterpart in the reference. */
+int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n);
+
+/* Pack int4 weights held one per int8 byte (values -8..7, the reference's int4 convention:
+ * include/ck/utility/data_type.hpp:10-14, example/64_fpAintB_gemm/run_gemm_example.inc:8-10)
+ * into WQ_I4_PACKED.  Source: (K,N) column-major, element (k,n) at q[n*ldq + k] (device memory).
+ * Destination: column n at out + n*ld_bytes, K/2 bytes; nibble = q + 8 (offset binary, the int4
+ * analogue of example/64_fpAintB_gemm/common.hpp:66-74); inside each little-endian 32-bit word
+ * (8 consecutive k starting at 8g) nibble p (bits 4p..4p+3) holds k = 8g + 2p for p < 4 and
+ * k = 8g + 2(p-4) + 1 for p >= 4.  K must be a multiple of 8.  Values are not range-checked on
+ * the device (they are masked to 4 bits after the +8). */
+int wqgemm_pack_int4(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t* out,
+                     int32_t ld_bytes, void* stream);
+
+/* Host-memory variant of wqgemm_pack_int4 for offline weight preparation; additionally returns
+ * WQ_ERR_INVALID if a value lies outside -8..7. */
+int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t* out,
+                          int32_t ld_bytes);
+
+/* Sum k_batch fp32 partials [k_batch][M][N] (row-major, ld = N) in ascending batch order, apply
+ * p's epilogue and store p->c.  With k_batch == 1 this is the final convert/epilogue step after
+ * a multi-GPU reduction.  Replaces RunReduce
+ * (impl/device_gemm_xdl_cshuffle_v3r1.hpp:209-270). */
+int wqgemm_reduce_finalize(const wqgemm_problem* p, const float* partials, int32_t k_batch,
+                           void* stream);
+
+/* KRead of the split-K partition: ceil(K/(k_batch*granule))*granule
+ * (gridwise_gemm_xdl_cshuffle_v3.hpp:192-197). */
+int32_t wqgemm_splitk_kread(int32_t K, int32_t k_batch, int32_t granule);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WQGEMM_H */

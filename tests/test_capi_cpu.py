@@ -1,0 +1,80 @@
+"""CPU-only checks of the C-ABI surface: the library loads, exports every declared symbol,
+validates problems and packs int4 on the host.  No GPU call is made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from composable_kernel_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "wqgemm.h")).read()
+    declared = set(re.findall(r"\b(wqgemm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(capi.lib, name), name
+    assert "gfx950" in capi.version()
+
+
+def _problem(**kw):
+    fake = 0x10000  # never dereferenced by validation
+    d = dict(a=fake, b=fake, scale=fake, c=fake, M=4096, N=4096, K=4096)
+    d.update(kw)
+    return capi.fpAintB_problem(d.pop("a"), d.pop("b"), d.pop("scale"), d.pop("c"), d.pop("M"), d.pop("N"),
+                                d.pop("K"), **d)
+
+
+def test_is_supported_and_routes():
+    p = _problem()
+    assert capi.is_supported(p)
+    assert capi.kernel_name(p) == "wq_gemm_mfma_128"
+    assert "DeviceFpAintBGemm_Mfma_gfx950" in capi.type_string(p)
+    # ragged shapes fall back to the generic HIP kernel (still supported)
+    p = _problem(M=33, N=17, K=72, lda=80, ldb=88, ldc=24)
+    assert capi.is_supported(p) and capi.kernel_name(p) == "wq_gemm_generic"
+    # packed int4 needs K % 8 == 0 and a K-contiguous B
+    assert not capi.is_supported(_problem(K=100, lda=100, ldb=104))
+    assert not capi.is_supported(_problem(b_layout=capi.ROW_MAJOR))
+    # null pointers / bad sizes are invalid, not crashes
+    assert not capi.is_supported(_problem(a=None))
+    assert not capi.is_supported(_problem(M=0))
+    assert not capi.is_supported(_problem(lda=100))
+    # C dtype must follow A for the 16-bit paths
+    assert not capi.is_supported(_problem(c_dtype=capi.BF16))
+    # launching an unsupported problem returns a status, never raises from C
+    bad = _problem(K=100, lda=100, ldb=104)
+    assert capi.lib.wqgemm_launch(C.byref(bad), None, None) == capi.ERR_UNSUPPORTED
+    assert b"int4" in capi.lib.wqgemm_last_error()
+
+
+def test_splitk_workspace_and_kread():
+    assert capi.splitk_kread(65536, 8) == 8192
+    assert capi.splitk_kread(437, 3, 8) == 152
+    p = _problem(k_batch=4)
+    assert capi.workspace_bytes(p) == 4 * 4096 * 4096 * 4
+    assert capi.workspace_bytes(_problem()) == 0
+    # a K-slice launch writes fp32 partials straight to C: no workspace, c_dtype must be F32
+    p = _problem(k_begin=8192, k_end=16384, K=65536, c_dtype=capi.F32)
+    assert capi.is_supported(p) and capi.workspace_bytes(p) == 0
+    assert not capi.is_supported(_problem(k_begin=8192, k_end=16384, K=65536))
+    # split-K without a workspace is reported as such
+    p = _problem(k_batch=2)
+    assert capi.lib.wqgemm_launch(C.byref(p), None, None) == capi.ERR_WORKSPACE
+
+
+def test_pack_int4_host_matches_checker(port):
+    rng = np.random.default_rng(2)
+    K, N = 128, 7
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    np.testing.assert_array_equal(capi.pack_int4_host(q, K, N), port.pack_int4(q, K, N))
+    bad = q.copy()
+    bad[3, 5] = -9
+    try:
+        capi.pack_int4_host(bad, K, N)
+        raise AssertionError("out-of-range value accepted")
+    except capi.WqError as e:
+        assert e.status == capi.ERR_INVALID

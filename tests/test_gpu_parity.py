@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP kernels, driven through the C ABI, against the CPU checker
+(oracle/wq_oracle.c) and the committed golden vectors produced by the reference's host code.
+
+Bars: bit-exact for integer/index work (int4 packing, int8 requant GEMM, the generic kernel whose
+fp32 accumulation runs in the reference's ascending-k order, and every kernel on integer-valued
+inputs); for floating-point inputs on the MFMA kernels the accumulate order differs, so the bar is
+ck::utils::check_err's defaults for the output type (half / bf16: rtol 1e-3, atol 1e-3 --
+library/include/ck/library/utility/check_err.hpp:82-86,133-137) unless a test states otherwise.
+"""
+import numpy as np
+import pytest
+import torch
+
+from composable_kernel_amd import capi
+from gpu_util import (bf16_bits, bits_to_f32, check_err, dev, f16_bits, host_u16, pack_on_device,
+                      run_fpaintb)
+
+pytestmark = pytest.mark.gpu
+
+MFMA = "wq_gemm_mfma_128"
+GENERIC = "wq_gemm_generic"
+
+
+def test_pack_int4_device_bit_exact(port):
+    rng = np.random.default_rng(0)
+    for K, N in ((64, 3), (4096, 257), (8, 1)):
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        got = pack_on_device(q, K, N).cpu().numpy()
+        np.testing.assert_array_equal(got, port.pack_int4(q, K, N))
+
+
+def test_mfma_layout_probe(port):
+    """A = shifted identity pattern, B asymmetric: catches transposed / permuted fragment maps."""
+    M = N = 128
+    K = 64
+    a = np.zeros((M, K), np.float16)
+    for m in range(M):
+        a[m, (m * 7 + 3) % K] = 1.0        # one 1 per row at a row-dependent k
+    q = np.zeros((N, K), np.int8)
+    for n in range(N):
+        for k in range(K):
+            q[n, k] = ((n * 5 + k * 3) % 16) - 8   # asymmetric in (n, k)
+    s = f16_bits(np.ones(N))
+    got = run_fpaintb(f16_bits(a), pack_on_device(q, K, N), s, M, N, K, expect_kernel=MFMA)
+    exp = port.fpAintB_gemm_f16(f16_bits(a), q, s, M, N, K, K, K, N).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_golden_integer_case_exact_on_mfma(golden_gemm):
+    g = golden_gemm
+    M, N, K, lda, ldb, ldc = (int(v) for v in g["fpaintb_int_shape"])
+    q = np.ascontiguousarray(g["fpaintb_int_b"][:, :K])
+    got = run_fpaintb(g["fpaintb_int_a"], pack_on_device(q, K, N), g["fpaintb_int_s"], M, N, K,
+                      lda=lda, ldc=ldc, expect_kernel=MFMA)
+    np.testing.assert_array_equal(got.reshape(-1)[: g["fpaintb_int_c"].size], g["fpaintb_int_c"])
+    assert ldc == N
+
+
+@pytest.mark.parametrize("tag", ["fpaintb_real", "fpaintb_ragged"])
+def test_golden_cases_generic_kernel_bit_exact(golden_gemm, tag):
+    """The generic kernel accumulates in ascending k with separate multiply/add: bit-exact."""
+    g = golden_gemm
+    M, N, K, lda, ldb, ldc = (int(v) for v in g[f"{tag}_shape"])
+    q = np.ascontiguousarray(g[f"{tag}_b"][:, :K])
+    got = run_fpaintb(g[f"{tag}_a"], pack_on_device(q, K, N), g[f"{tag}_s"], M, N, K, lda=lda, ldc=ldc,
+                      expect_kernel=GENERIC)
+    exp = np.zeros(M * ldc, np.uint16)
+    exp[: g[f"{tag}_c"].size] = g[f"{tag}_c"]
+    # compare only the M x N window (the padding columns of ldc keep their poison)
+    np.testing.assert_array_equal(got[:, :N], exp.reshape(M, ldc)[:, :N])
+    assert (got[:, N:] == 0x7BFF).all()
+
+
+def test_golden_i8_weights_generic(golden_gemm):
+    g = golden_gemm
+    M, N, K, lda, ldb, ldc = (int(v) for v in g["fpaintb_i8_shape"])
+    b = g["fpaintb_i8_b"]
+    exp = g["fpaintb_i8_c"].reshape(M, N)
+    got = run_fpaintb(g["fpaintb_i8_a"], b, g["fpaintb_i8_s"], M, N, K, b_dtype=capi.I8, expect_kernel=GENERIC)
+    np.testing.assert_array_equal(got, exp)
+    bu = (b.astype(np.int16) + 128).astype(np.uint8)   # example/64's UnsignedWeightPreprocessor
+    got = run_fpaintb(g["fpaintb_i8_a"], bu, g["fpaintb_i8_s"], M, N, K, b_dtype=capi.U8_OFFSET,
+                      expect_kernel=GENERIC)
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (128, 256, 1024)])
+def test_fp16_int4_mfma_vs_checker(port, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    a = f16_bits(rng.uniform(-1, 1, (M, K)))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    got = run_fpaintb(a, pack_on_device(q, K, N), s, M, N, K, expect_kernel=MFMA)
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+    # integer-valued inputs: every partial sum is exact in fp32, so any order gives the same bits
+    a = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+    s = f16_bits(rng.integers(1, 4, N).astype(np.float32))
+    got = run_fpaintb(a, pack_on_device(q, K, N), s, M, N, K, expect_kernel=MFMA)
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("b_dtype", [capi.I8, capi.U8_OFFSET])
+def test_fp16_int8_mfma(port, b_dtype):
+    rng = np.random.default_rng(11)
+    M, N, K = 128, 256, 256
+    q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    b = q if b_dtype == capi.I8 else (q.astype(np.int16) + 128).astype(np.uint8)
+    a = f16_bits(np.round(rng.uniform(-1, 1, (M, K))))
+    s = f16_bits(rng.integers(1, 3, N).astype(np.float32))
+    got = run_fpaintb(a, b, s, M, N, K, b_dtype=b_dtype, expect_kernel=MFMA)
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+    a = f16_bits(rng.uniform(-1, 1, (M, K)))
+    s = f16_bits(rng.uniform(2.0 ** -10, 2.0 ** -7, N))
+    got = run_fpaintb(a, b, s, M, N, K, b_dtype=b_dtype, expect_kernel=MFMA)
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
+def test_bf16_int8_golden_generic_all_epilogues(golden_gemm):
+    """Config C3 semantics on the golden case (48 x 64 x 128 -> generic kernel)."""
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    for ep, kind in ((0, capi.EPI_PASSTHROUGH), (1, capi.EPI_FASTGELU), (2, capi.EPI_MULTIPLY_ADD_FASTGELU)):
+        got = run_fpaintb(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
+                          epilogue=kind, d0=g["bf16_d0"], d1=g["bf16_d1"], expect_kernel=GENERIC)
+        exp = g[f"bf16_e_col_ep{ep}"].reshape(M, N)
+        if ep == 0:
+            np.testing.assert_array_equal(got, exp)   # same order, truncating store: bit-exact
+        else:
+            # FastGelu uses fp32 expf on the device vs double exp on the host: allow one bf16 ulp
+            d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+            assert d.max() <= 1, d.max()
+    # row-major B (example/60's layout) through the generic kernel
+    brow = np.ascontiguousarray(g["bf16_bcol"].T)
+    got = run_fpaintb(g["bf16_a"], brow, g["bf16_s"], M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
+                      epilogue=capi.EPI_FASTGELU, b_layout=capi.ROW_MAJOR, ldb=N, expect_kernel=GENERIC)
+    d = np.abs(got.astype(np.int32) - g["bf16_e_row_ep1"].reshape(M, N).astype(np.int32))
+    assert d.max() <= 1
+
+
+def test_bf16_int8_mfma(port):
+    rng = np.random.default_rng(5)
+    M, N, K = 256, 256, 512
+    q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    # exact set
+    a = bf16_bits(np.round(rng.uniform(-1, 1, (M, K))))
+    s = bf16_bits(rng.integers(1, 3, N).astype(np.float32))
+    got = run_fpaintb(a, q, s, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, expect_kernel=MFMA)
+    exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+    # realistic set: bf16 output is a truncation, so a different fp32 summation order can move the
+    # result by one bf16 ulp (2^-8 relative); bar = 1 ulp on every element + check_err 1e-2.
+    a = bf16_bits(rng.uniform(-1, 1, (M, K)))
+    s = bf16_bits(rng.uniform(2.0 ** -10, 2.0 ** -7, N))
+    got = run_fpaintb(a, q, s, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, expect_kernel=MFMA)
+    exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+    check_err(bits_to_f32(got, capi.BF16), bits_to_f32(exp, capi.BF16), 1e-2, 1e-3)
+    # bf16 x packed int4 (exact set)
+    q4 = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    a = bf16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+    s = bf16_bits(rng.integers(1, 3, N).astype(np.float32))
+    got = run_fpaintb(a, pack_on_device(q4, K, N), s, M, N, K, a_dtype=capi.BF16, expect_kernel=MFMA)
+    exp = port.gemm_bf16_i8(a, q4, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_c1_int8_requant_gemm_exact(golden_gemm, port):
+    """example/14 problem (M=N=K=256, srand(1) inputs, requant 0.03) on the GPU: atol 0."""
+    M = N = K = 256
+    a = port.generator2_i8(M, K, K, 1, -128, 127, seed=1)
+    b = port.generator2_i8(K, N, 1, K, -128, 127, seed=-1)
+    a_t, b_t = dev(a), dev(b)
+    e_t = torch.zeros((M, N), dtype=torch.int8, device="cuda")
+    p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), None, e_t.data_ptr(), M, N, K, a_dtype=capi.I8,
+                             b_dtype=capi.I8, c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=0.03)
+    assert capi.is_supported(p)
+    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(e_t.cpu().numpy(), golden_gemm["c1_e"])
+
+
+def test_f8_int4_multiply_multiply_generic(golden_gemm):
+    """Config C5 semantics (fp8 FNUZ bytes x int4, d0[n] * d1[m], optional FastGelu), golden case."""
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    bp = pack_on_device(np.ascontiguousarray(g["f8_b"]), K, N)
+    for key, kind in (("f8_e_mm", capi.EPI_MULTIPLY_MULTIPLY), ("f8_e_mm_gelu", capi.EPI_MULTIPLY_MULTIPLY_FASTGELU)):
+        got = run_fpaintb(g["f8_a"], bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=kind,
+                          d0=g["f8_d0"], d1=g["f8_d1"], expect_kernel=GENERIC)
+        exp = g[key].reshape(M, N)
+        if kind == capi.EPI_MULTIPLY_MULTIPLY:
+            np.testing.assert_array_equal(got, exp)
+        else:
+            check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("k_batch", [2, 3, 5, 8])
+def test_splitk_in_gpu(port, k_batch):
+    """k_batches of the reference's split-K tests (test/gemm_split_k/test_gemm_splitk_util.hpp:36-87)."""
+    rng = np.random.default_rng(k_batch)
+    M, N, K = 128, 128, 1024
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    a = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+    s = f16_bits(rng.integers(1, 3, N).astype(np.float32))
+    got = run_fpaintb(a, bp, s, M, N, K, k_batch=k_batch, expect_kernel=MFMA)
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+    a = f16_bits(rng.uniform(-1, 1, (M, K)))
+    s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    got = run_fpaintb(a, bp, s, M, N, K, k_batch=k_batch, expect_kernel=MFMA)
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
+def test_k_slices_then_reduce_finalize(port):
+    """The multi-GPU split-K data path on one GPU: G slice launches -> fp32 partials -> sum -> finalize."""
+    rng = np.random.default_rng(21)
+    M, N, K, G = 128, 256, 1024, 4
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    a = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+    s = f16_bits(rng.integers(1, 3, N).astype(np.float32))
+    a_t, s_t = dev(a), dev(s)
+    parts = torch.zeros((G, M, N), dtype=torch.float32, device="cuda")
+    kread = capi.splitk_kread(K, G)
+    stream = torch.cuda.current_stream().cuda_stream
+    for gidx in range(G):
+        p = capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), parts[gidx].data_ptr(), M, N, K,
+                                 k_begin=gidx * kread, k_end=min(K, (gidx + 1) * kread), c_dtype=capi.F32)
+        assert capi.kernel_name(p) == MFMA
+        capi.launch(p, None, stream)
+    torch.cuda.synchronize()
+    # each partial equals the checker's partial exactly (integer inputs)
+    for gidx in range(G):
+        exp = port.fpAintB_partial(a, q, s, M, N, K, K, gidx * kread, min(K, (gidx + 1) * kread))
+        np.testing.assert_array_equal(parts[gidx].cpu().numpy(), exp)
+    total = parts.sum(dim=0).contiguous()      # stands in for the RCCL reduce
+    c_t = torch.zeros((M, N), dtype=torch.int16, device="cuda")
+    p = capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), c_t.data_ptr(), M, N, K)
+    capi.reduce_finalize(p, total.data_ptr(), 1, stream)
+    torch.cuda.synchronize()
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    np.testing.assert_array_equal(host_u16(c_t), exp)
+    # reduce_finalize summing the slabs itself (k_batch = G)
+    c_t.zero_()
+    capi.reduce_finalize(p, parts.data_ptr(), G, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host_u16(c_t), exp)
+
+
+def test_full_size_c2_properties(port):
+    """BASELINE config 2 at full size (M=N=K=4096): a 32-row block against the CPU checker, the
+    whole output against the independent generic HIP kernel, and exactness on integer inputs."""
+    rng = np.random.default_rng(4096)
+    M = N = K = 4096
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    a = f16_bits(rng.uniform(-1, 1, (M, K)))
+    s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    got = run_fpaintb(a, bp, s, M, N, K, expect_kernel=MFMA)
+    rows = slice(1000, 1032)
+    exp = port.fpAintB_gemm_f16(np.ascontiguousarray(a[rows]), q, s, 32, N, K, K, K, N).reshape(32, N)
+    check_err(bits_to_f32(got[rows], capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+    # independent HIP path: generic kernel (bit-exact with the checker at small sizes) on a row block
+    # whose M = 96 is not a tile multiple, so the dispatcher must pick it
+    a96 = np.ascontiguousarray(a[2048:2048 + 96])
+    gen = run_fpaintb(a96, bp, s, 96, N, K, expect_kernel=GENERIC)
+    check_err(bits_to_f32(got[2048:2048 + 96], capi.F16), bits_to_f32(gen, capi.F16), 1e-3, 1e-3)
+    # integer-valued inputs at full size: the MFMA kernel must equal the generic kernel bit for bit
+    ai = f16_bits(np.round(rng.uniform(-1, 1, (M, K))))
+    si = f16_bits(rng.integers(1, 3, N).astype(np.float32))
+    got = run_fpaintb(ai, bp, si, M, N, K, expect_kernel=MFMA)
+    gen = run_fpaintb(np.ascontiguousarray(ai[512:512 + 96]), bp, si, 96, N, K, expect_kernel=GENERIC)
+    np.testing.assert_array_equal(got[512:512 + 96], gen)
+    # linearity in the scale: doubling every scale doubles the output exactly (power of two)
+    got2 = run_fpaintb(ai, bp, f16_bits(2 * si.view(np.float16).astype(np.float32)), M, N, K)
+    np.testing.assert_array_equal(bits_to_f32(got2, capi.F16), 2 * bits_to_f32(got, capi.F16))
