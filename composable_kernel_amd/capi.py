@@ -9,6 +9,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64 (same soname as the system ROCm one).  Loading it first makes the
+# dynamic loader bind libwqgemm.so to that already-loaded runtime, so the process holds exactly one
+# HIP runtime and torch-allocated device pointers are valid in our launches.  Loading ours first
+# would bring in a second runtime that cannot see the device.
+import torch  # noqa: F401  (must precede the CDLL below)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libwqgemm.so")
 
