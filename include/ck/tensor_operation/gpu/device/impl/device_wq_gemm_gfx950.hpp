@@ -1,0 +1,450 @@
+// Concrete gfx950 (MI355X) operators of the weight-quantized GEMM engine behind Composable
+// Kernel's abstract client interfaces.  Host-only C++: every operator captures the problem into a
+// `wqgemm_problem` and calls the C ABI of libwqgemm.so (include/wqgemm.h); no device code is
+// compiled from this header, so a client needs only a host compiler and the HIP runtime headers.
+//
+// The header includes the abstract interfaces by their CK paths.  Built against this tree they
+// resolve to the facade (include/wqgemm/ck_facade.hpp); overlaid on a CK checkout they resolve to
+// CK's own headers, and these operators become additional instances next to CK's.
+//
+//   DeviceFpAintBGemm_Mfma_gfx950        : DeviceGemm_dequantB     (example/64_fpAintB_gemm)
+//        stands where DeviceFpAintBGemm_Wmma_CShuffle does
+//        (include/ck/tensor_operation/gpu/device/impl/device_fpAintB_gemm_wmma.hpp:70-710)
+//   DeviceGemmQuantization_gfx950        : DeviceGemmMultipleD     (example/14, client_example/09)
+//        stands where DeviceGemmMultipleD_Xdl_CShuffle<int8...> does
+//        (impl/device_gemm_multiple_d_xdl_cshuffle.hpp)
+//   DeviceGemmMultiABD_WeightQuant_gfx950: DeviceGemmMultipleABD   (example/60, client_example/30)
+//        stands where DeviceGemmMultipleABD_Xdl_CShuffle<(bf16),(int8,bf16)> does
+//        (impl/device_gemm_multiple_abd_xdl_cshuffle.hpp)
+//   DeviceGemmMultiplyMultiply_WeightQuant_gfx950 : DeviceGemmMultipleD (example/65)
+//        stands where DeviceGemmMultiD_Xdl_CShuffle_V3<f8,f8,(f32,f32)> does
+//        (impl/device_gemm_multiple_d_xdl_cshuffle_v3.hpp)
+//
+// Conventions kept from the reference (device_fpAintB_gemm_wmma.hpp:424-433,497-501,594-630):
+// Argument holds raw non-owning pointers and copies of the functors; IsSupportedArgument returns
+// false for problems the engine cannot run; Invoker::Run throws std::runtime_error on an
+// unsupported argument and on HIP failures, returns the mean kernel time in ms when
+// StreamConfig::time_kernel_ is set and 0 after one asynchronous launch otherwise.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+
+#include "ck/ck.hpp"
+#include "ck/utility/data_type.hpp"
+#include "ck/tensor_operation/gpu/device/tensor_layout.hpp"
+#include "ck/tensor_operation/gpu/device/device_gemm_dequantB.hpp"
+#include "ck/tensor_operation/gpu/device/device_gemm_multiple_d.hpp"
+#include "ck/tensor_operation/gpu/device/device_gemm_multiple_abd.hpp"
+#include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
+
+#include "wqgemm.h"
+
+namespace ck {
+
+// Storage tag for packed int4 weights: two offset-binary nibbles per byte in the layout
+// documented at wqgemm_pack_int4 (include/wqgemm.h).  Strides of such a tensor still count
+// logical elements.
+struct wq_int4x2_t
+{
+    uint8_t data;
+};
+
+namespace tensor_operation {
+namespace device {
+
+namespace wq_detail {
+
+template <typename T>
+struct dtype_of;
+template <>
+struct dtype_of<ck::half_t>
+{
+    static constexpr int value = WQ_F16;
+};
+template <>
+struct dtype_of<ck::bhalf_t>
+{
+    static constexpr int value = WQ_BF16;
+};
+template <>
+struct dtype_of<ck::f8_t>
+{
+    static constexpr int value = WQ_F8_FNUZ;
+};
+template <>
+struct dtype_of<float>
+{
+    static constexpr int value = WQ_F32;
+};
+template <>
+struct dtype_of<int8_t>
+{
+    static constexpr int value = WQ_I8;
+};
+template <>
+struct dtype_of<uint8_t>
+{
+    static constexpr int value = WQ_U8_OFFSET;
+};
+template <>
+struct dtype_of<ck::wq_int4x2_t>
+{
+    static constexpr int value = WQ_I4_PACKED;
+};
+template <>
+struct dtype_of<int32_t>
+{
+    static constexpr int value = WQ_I32;
+};
+
+template <typename Layout>
+constexpr int layout_of()
+{
+    return std::is_same_v<Layout, ck::tensor_layout::gemm::RowMajor> ? WQ_ROW_MAJOR : WQ_COL_MAJOR;
+}
+
+template <typename Op>
+constexpr int unary_epilogue_of()
+{
+    namespace ew = ck::tensor_operation::element_wise;
+    if constexpr(std::is_same_v<Op, ew::PassThrough>)
+        return WQ_EPI_PASSTHROUGH;
+    else if constexpr(std::is_same_v<Op, ew::FastGelu>)
+        return WQ_EPI_FASTGELU;
+    else
+        return -1;
+}
+
+inline bool device_is_gfx950()
+{
+    int dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return false;
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return false;
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+inline bool supported(const wqgemm_problem& prob)
+{
+    if(!device_is_gfx950())
+    {
+        std::cout << "DeviceOp err: Arch" << std::endl; // the reference's wording for a wrong target
+        return false;
+    }
+    return wqgemm_is_supported(&prob) != 0;
+}
+
+inline float run(const wqgemm_problem& prob, void* workspace, const StreamConfig& cfg, const char* who)
+{
+    if(wqgemm_is_supported(&prob) == 0)
+        throw std::runtime_error(std::string("wrong! ") + who + " has invalid setting: " + wqgemm_last_error());
+    if(cfg.time_kernel_)
+    {
+        float ms     = 0.f;
+        const int rc = wqgemm_run_timed(&prob, workspace, cfg.stream_id_, cfg.cold_niters_, cfg.nrepeat_, &ms);
+        if(rc != WQ_OK)
+            throw std::runtime_error(std::string(who) + ": " + wqgemm_last_error());
+        return ms;
+    }
+    const int rc = wqgemm_launch(&prob, workspace, cfg.stream_id_);
+    if(rc != WQ_OK)
+        throw std::runtime_error(std::string(who) + ": " + wqgemm_last_error());
+    return 0.f;
+}
+
+inline std::string type_string(const wqgemm_problem& prob)
+{
+    char buf[512];
+    wqgemm_type_string(&prob, buf, sizeof(buf));
+    return buf;
+}
+
+// Argument / Invoker shared by every operator below.
+struct Argument : public BaseArgument
+{
+    wqgemm_problem prob{};
+};
+
+struct Invoker : public BaseInvoker
+{
+    explicit Invoker(const char* who) : who_(who) {}
+    float Run(const Argument& arg, const StreamConfig& cfg = StreamConfig{})
+    {
+        return run(arg.prob, arg.p_workspace_, cfg, who_);
+    }
+    float Run(const BaseArgument* p_arg, const StreamConfig& cfg = StreamConfig{}) override
+    {
+        return Run(*dynamic_cast<const Argument*>(p_arg), cfg);
+    }
+    const char* who_;
+};
+
+} // namespace wq_detail
+
+// ---------------------------------------------------------------------------------------------
+// C[M,N] = c_op( A[M,K] * (cvt_A(B[K,N]) * scale[N]) )      fp16 / bf16 activations
+// ---------------------------------------------------------------------------------------------
+template <typename ALayout, typename BLayout, typename CLayout, typename ADataType, typename BDataType,
+          typename ScaleDataType, typename CDataType, typename AElementwiseOperation,
+          typename BElementwiseOperation, typename CElementwiseOperation>
+struct DeviceFpAintBGemm_Mfma_gfx950
+    : public DeviceGemm_dequantB<ALayout, BLayout, CLayout, ADataType, BDataType, CDataType,
+                                 AElementwiseOperation, BElementwiseOperation, CElementwiseOperation>
+{
+    using Argument = wq_detail::Argument;
+    using Invoker  = wq_detail::Invoker;
+
+    static_assert(wq_detail::unary_epilogue_of<CElementwiseOperation>() >= 0,
+                  "CElementwiseOperation must be PassThrough or FastGelu");
+
+    static Argument MakeArgument(const ADataType* p_a, const BDataType* p_b, const ScaleDataType* p_scale,
+                                 CDataType* p_c, index_t M, index_t N, index_t K, index_t StrideA,
+                                 index_t StrideB, index_t StrideC, AElementwiseOperation,
+                                 BElementwiseOperation, CElementwiseOperation, index_t KBatch = 1)
+    {
+        Argument arg;
+        wqgemm_problem& p = arg.prob;
+        p.a_dtype         = wq_detail::dtype_of<ADataType>::value;
+        p.b_dtype         = wq_detail::dtype_of<BDataType>::value;
+        p.scale_dtype     = wq_detail::dtype_of<ScaleDataType>::value;
+        p.c_dtype         = wq_detail::dtype_of<CDataType>::value;
+        p.a_layout        = wq_detail::layout_of<ALayout>();
+        p.b_layout        = wq_detail::layout_of<BLayout>();
+        p.c_layout        = wq_detail::layout_of<CLayout>();
+        p.M = M, p.N = N, p.K = K;
+        p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideC;
+        p.a = p_a, p.b = p_b, p.scale = p_scale, p.c = p_c;
+        p.epilogue = wq_detail::unary_epilogue_of<CElementwiseOperation>();
+        p.k_batch  = KBatch;
+        return arg;
+    }
+
+    static Invoker MakeInvoker() { return Invoker{"DeviceFpAintBGemm_Mfma_gfx950"}; }
+
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+
+    std::unique_ptr<BaseArgument> MakeArgumentPointer(const void* p_a, const void* p_b, const void* p_scale,
+                                                      void* p_c, index_t M, index_t N, index_t K,
+                                                      index_t StrideA, index_t StrideB, index_t StrideC,
+                                                      AElementwiseOperation a_op, BElementwiseOperation b_op,
+                                                      CElementwiseOperation c_op) override
+    {
+        return std::make_unique<Argument>(MakeArgument(
+            static_cast<const ADataType*>(p_a), static_cast<const BDataType*>(p_b),
+            static_cast<const ScaleDataType*>(p_scale), static_cast<CDataType*>(p_c), M, N, K, StrideA,
+            StrideB, StrideC, a_op, b_op, c_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+
+    size_t GetWorkSpaceSize(const BaseArgument* p_arg) const override
+    {
+        return wqgemm_workspace_bytes(&dynamic_cast<const Argument*>(p_arg)->prob);
+    }
+
+    std::string GetTypeString() const override
+    {
+        wqgemm_problem p{};
+        p.a_dtype = wq_detail::dtype_of<ADataType>::value;
+        p.b_dtype = wq_detail::dtype_of<BDataType>::value;
+        p.c_dtype = wq_detail::dtype_of<CDataType>::value;
+        return std::string("DeviceFpAintBGemm_Mfma_gfx950<") + (p.a_dtype == WQ_BF16 ? "BF16" : "F16") + ", " +
+               (p.b_dtype == WQ_I4_PACKED ? "I4x2" : (p.b_dtype == WQ_I8 ? "I8" : "U8")) +
+               ", LdsDma, DequantInRegister, Mfma16x16x32>";
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// E[M,N] = Activation_Mul_Clamp( A[M,K] int8 * B[K,N] int8 )              int8 requantised GEMM
+// ---------------------------------------------------------------------------------------------
+template <typename ALayout, typename BLayout, typename ELayout, typename CDEElementwiseOperation>
+struct DeviceGemmQuantization_gfx950
+    : public DeviceGemmMultipleD<ALayout, BLayout, ck::Tuple<>, ELayout, int8_t, int8_t, ck::Tuple<>, int8_t,
+                                 element_wise::PassThrough, element_wise::PassThrough, CDEElementwiseOperation>
+{
+    using Argument    = wq_detail::Argument;
+    using Invoker     = wq_detail::Invoker;
+    using PassThrough = element_wise::PassThrough;
+
+    static Argument MakeArgument(const void* p_a, const void* p_b, std::array<const void*, 0>, void* p_e,
+                                 index_t M, index_t N, index_t K, index_t StrideA, index_t StrideB,
+                                 std::array<index_t, 0>, index_t StrideE, PassThrough, PassThrough,
+                                 CDEElementwiseOperation cde_op)
+    {
+        Argument arg;
+        wqgemm_problem& p = arg.prob;
+        p.a_dtype = p.b_dtype = p.c_dtype = WQ_I8;
+        p.scale_dtype                     = WQ_F32;
+        p.a_layout                        = wq_detail::layout_of<ALayout>();
+        p.b_layout                        = wq_detail::layout_of<BLayout>();
+        p.c_layout                        = wq_detail::layout_of<ELayout>();
+        p.M = M, p.N = N, p.K = K;
+        p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideE;
+        p.a = p_a, p.b = p_b, p.c = p_e;
+        p.epilogue      = WQ_EPI_ACT_MUL_CLAMP;
+        p.requant_scale = cde_op.requantScale_;
+        p.k_batch       = 1;
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmQuantization_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument> MakeArgumentPointer(const void* p_a, const void* p_b,
+                                                      std::array<const void*, 0> p_ds, void* p_e, index_t M,
+                                                      index_t N, index_t K, index_t StrideA, index_t StrideB,
+                                                      std::array<index_t, 0> StrideDs, index_t StrideE,
+                                                      PassThrough a_op, PassThrough b_op,
+                                                      CDEElementwiseOperation cde_op) override
+    {
+        return std::make_unique<Argument>(
+            MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE, a_op, b_op, cde_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    std::string GetTypeString() const override { return "DeviceGemmQuantization_gfx950<I8, I8, I8, Activation_Mul_Clamp>"; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// E = cde_op( A0[M,K] bf16 * Multiply(B0[K,N] int8, B1[N] bf16) )                 multi-ABD form
+// ---------------------------------------------------------------------------------------------
+template <typename A0Layout, typename B0Layout, typename ELayout, typename A0DataType, typename B0DataType,
+          typename B1DataType, typename EDataType, typename CDEElementwiseOperation>
+struct DeviceGemmMultiABD_WeightQuant_gfx950
+    : public DeviceGemmMultipleABD<ck::Tuple<A0Layout>, ck::Tuple<B0Layout, B0Layout>, ck::Tuple<>, ELayout,
+                                   ck::Tuple<A0DataType>, ck::Tuple<B0DataType, B1DataType>, ck::Tuple<>,
+                                   EDataType, element_wise::PassThrough, element_wise::Multiply,
+                                   CDEElementwiseOperation>
+{
+    using Argument    = wq_detail::Argument;
+    using Invoker     = wq_detail::Invoker;
+    using PassThrough = element_wise::PassThrough;
+    using Multiply    = element_wise::Multiply;
+    static_assert(wq_detail::unary_epilogue_of<CDEElementwiseOperation>() >= 0,
+                  "CDEElementwiseOperation must be PassThrough or FastGelu");
+
+    static Argument MakeArgument(std::array<const void*, 1> p_as, std::array<const void*, 2> p_bs,
+                                 std::array<const void*, 0>, void* p_e, index_t M, index_t N, index_t K,
+                                 std::array<index_t, 1> StrideAs, std::array<index_t, 2> StrideBs,
+                                 std::array<index_t, 0>, index_t StrideE, PassThrough, Multiply,
+                                 CDEElementwiseOperation)
+    {
+        Argument arg;
+        wqgemm_problem& p = arg.prob;
+        p.a_dtype         = wq_detail::dtype_of<A0DataType>::value;
+        p.b_dtype         = wq_detail::dtype_of<B0DataType>::value;
+        p.scale_dtype     = wq_detail::dtype_of<B1DataType>::value;
+        p.c_dtype         = wq_detail::dtype_of<EDataType>::value;
+        p.a_layout        = wq_detail::layout_of<A0Layout>();
+        p.b_layout        = wq_detail::layout_of<B0Layout>();
+        p.c_layout        = wq_detail::layout_of<ELayout>();
+        p.M = M, p.N = N, p.K = K;
+        p.lda = StrideAs[0], p.ldb = StrideBs[0], p.ldc = StrideE; // StrideBs[1] == 0: per-column scale
+        p.a = p_as[0], p.b = p_bs[0], p.scale = p_bs[1], p.c = p_e;
+        p.epilogue = wq_detail::unary_epilogue_of<CDEElementwiseOperation>();
+        p.k_batch  = 1;
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiABD_WeightQuant_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument>
+    MakeArgumentPointer(std::array<const void*, 1> p_as, std::array<const void*, 2> p_bs,
+                        std::array<const void*, 0> p_ds, void* p_e, index_t M, index_t N, index_t K,
+                        std::array<index_t, 1> StrideAs, std::array<index_t, 2> StrideBs,
+                        std::array<index_t, 0> StrideDs, index_t StrideE, PassThrough a_op, Multiply b_op,
+                        CDEElementwiseOperation cde_op) override
+    {
+        return std::make_unique<Argument>(MakeArgument(p_as, p_bs, p_ds, p_e, M, N, K, StrideAs, StrideBs,
+                                                       StrideDs, StrideE, a_op, b_op, cde_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    std::string GetTypeString() const override { return "DeviceGemmMultiABD_WeightQuant_gfx950<BF16, I8, Multiply>"; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// E = cde_op( A[M,K] fp8 * B[K,N] int4/int8, D0[N] f32, D1[M] f32 )       multiply_multiply form
+// ---------------------------------------------------------------------------------------------
+template <typename ALayout, typename BLayout, typename ELayout, typename ADataType, typename BDataType,
+          typename EDataType, typename CDEElementwiseOperation>
+struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
+    : public DeviceGemmMultipleD<ALayout, BLayout, ck::Tuple<ELayout, ELayout>, ELayout, ADataType, BDataType,
+                                 ck::Tuple<float, float>, EDataType, element_wise::PassThrough,
+                                 element_wise::PassThrough, CDEElementwiseOperation>
+{
+    using Argument    = wq_detail::Argument;
+    using Invoker     = wq_detail::Invoker;
+    using PassThrough = element_wise::PassThrough;
+
+    static constexpr int epilogue()
+    {
+        if constexpr(std::is_same_v<CDEElementwiseOperation, element_wise::MultiplyMultiply>)
+            return WQ_EPI_MULTIPLY_MULTIPLY;
+        else
+            return WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU;
+    }
+
+    // D0: per-column (row-major, stride 0); D1: per-row (column-major, stride 0) --
+    // example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8.cpp:43-47,152-153
+    static Argument MakeArgument(const void* p_a, const void* p_b, std::array<const void*, 2> p_ds, void* p_e,
+                                 index_t M, index_t N, index_t K, index_t StrideA, index_t StrideB,
+                                 std::array<index_t, 2>, index_t StrideE, PassThrough, PassThrough,
+                                 CDEElementwiseOperation)
+    {
+        Argument arg;
+        wqgemm_problem& p = arg.prob;
+        p.a_dtype         = wq_detail::dtype_of<ADataType>::value;
+        p.b_dtype         = wq_detail::dtype_of<BDataType>::value;
+        p.scale_dtype     = WQ_F32;
+        p.c_dtype         = wq_detail::dtype_of<EDataType>::value;
+        p.a_layout        = wq_detail::layout_of<ALayout>();
+        p.b_layout        = wq_detail::layout_of<BLayout>();
+        p.c_layout        = wq_detail::layout_of<ELayout>();
+        p.M = M, p.N = N, p.K = K;
+        p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideE;
+        p.a = p_a, p.b = p_b, p.c = p_e;
+        p.d0 = p_ds[0], p.d1 = p_ds[1];
+        p.epilogue = epilogue();
+        p.k_batch  = 1;
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiplyMultiply_WeightQuant_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument> MakeArgumentPointer(const void* p_a, const void* p_b,
+                                                      std::array<const void*, 2> p_ds, void* p_e, index_t M,
+                                                      index_t N, index_t K, index_t StrideA, index_t StrideB,
+                                                      std::array<index_t, 2> StrideDs, index_t StrideE,
+                                                      PassThrough a_op, PassThrough b_op,
+                                                      CDEElementwiseOperation cde_op) override
+    {
+        return std::make_unique<Argument>(
+            MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE, a_op, b_op, cde_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    std::string GetTypeString() const override { return "DeviceGemmMultiplyMultiply_WeightQuant_gfx950<F8, I4x2>"; }
+};
+
+} // namespace device
+} // namespace tensor_operation
+} // namespace ck
