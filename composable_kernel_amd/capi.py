@@ -24,6 +24,8 @@ OK, ERR_UNSUPPORTED, ERR_INVALID, ERR_HIP, ERR_WORKSPACE = range(5)
 F16, BF16, F8_FNUZ, F32, I8, U8_OFFSET, I4_PACKED, I32 = range(8)
 # wq_layout
 ROW_MAJOR, COL_MAJOR = 0, 1
+# wqgemm_problem.flags
+FLAG_TILE_128, FLAG_TILE_256 = 1, 2
 # wq_epilogue
 (EPI_PASSTHROUGH, EPI_FASTGELU, EPI_MULTIPLY_ADD_FASTGELU, EPI_MULTIPLY_MULTIPLY,
  EPI_MULTIPLY_MULTIPLY_FASTGELU, EPI_ACT_MUL_CLAMP) = range(6)
@@ -153,7 +155,7 @@ def splitk_kread(K: int, k_batch: int, granule: int = 64) -> int:
 
 def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, lda=None, ldb=None,
                     ldc=None, epilogue=EPI_PASSTHROUGH, d0=None, d1=None, k_batch=1, k_begin=0,
-                    k_end=0, c_dtype=None, b_layout=COL_MAJOR, a_layout=ROW_MAJOR, requant=0.0) -> Problem:
+                    k_end=0, c_dtype=None, b_layout=COL_MAJOR, a_layout=ROW_MAJOR, requant=0.0, flags=0) -> Problem:
     """Fill a Problem from raw device pointers (ints).  Strides default to packed tensors."""
     p = Problem()
     p.a_dtype, p.b_dtype, p.scale_dtype = a_dtype, b_dtype, a_dtype
@@ -166,5 +168,5 @@ def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, 
     p.a, p.b, p.scale, p.c = a, b, scale, c
     p.epilogue, p.requant_scale = epilogue, requant
     p.d0, p.d1 = d0, d1
-    p.k_batch, p.k_begin, p.k_end, p.flags = k_batch, k_begin, k_end, 0
+    p.k_batch, p.k_begin, p.k_end, p.flags = k_batch, k_begin, k_end, flags
     return p

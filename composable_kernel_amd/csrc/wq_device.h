@@ -262,6 +262,48 @@ __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, 
     }
 }
 
+// Same functors with the kind fixed at compile time (keeps unrolled epilogues small).
+template <int KIND>
+__device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x, int m, int n)
+{
+    if constexpr(KIND == 1)
+        return fast_gelu(x);
+    else if constexpr(KIND == 2)
+    {
+        const float t = x * load_d_as_f32(e.d0, n, e.c_dtype);
+        return fast_gelu(t + load_d_as_f32(e.d1, n, e.c_dtype));
+    }
+    else if constexpr(KIND == 3)
+    {
+        const float t = x * ((const float*)e.d0)[n];
+        return t * ((const float*)e.d1)[m];
+    }
+    else if constexpr(KIND == 4)
+    {
+        const float t = x * ((const float*)e.d0)[n];
+        return fast_gelu(t * ((const float*)e.d1)[m]);
+    }
+    else
+        return x;
+}
+
+// Store one accumulator fragment: lane holds C[m][n .. n+3] (fp32) of a row-major C.
+template <int KIND, bool BF16>
+__device__ __forceinline__ void store_c4(const EpilogueArgs& e, void* c, int ldc, f4_t v, int m, int n)
+{
+    uint16_t o[4];
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+    {
+        const float y = apply_epilogue_k<KIND>(e, v[j], m, n + j);
+        o[j]          = BF16 ? f32_to_bf16_trunc(y) : __builtin_bit_cast(uint16_t, (_Float16)y);
+    }
+    u2_t pk;
+    pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+    pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+    *(u2_t*)((uint16_t*)c + (size_t)m * ldc + n) = pk;
+}
+
 // quantization_operation.hpp:39-45 on an int32 accumulator
 __device__ __forceinline__ int8_t act_mul_clamp(float requant, int acc)
 {

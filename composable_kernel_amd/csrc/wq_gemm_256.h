@@ -1,0 +1,254 @@
+// 256 x 256 x 64 MFMA kernel of the weight-quantized GEMM engine (gfx950).
+//
+// One 512-thread workgroup (8 waves = 2 per SIMD) per 256 x 256 tile of C, one workgroup per CU.
+// Waves form a 2 (M) x 4 (N) grid; wave (wm, wn) owns rows [128 wm, +128) x columns [64 wn, +64):
+// 8 x 4 accumulator tiles of v_mfma_f32_16x16x32.  SIMD partners (waves w and w + 4) share the
+// weight columns and differ in the M half.
+//
+// Staging: A (256 rows x 128 B) and the packed weights (256 columns x 32 or 64 B) of one K tile
+// are moved HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of NBUF = 3 buffers, two K
+// tiles ahead of the MFMAs.  A wave waits for its own DMA of the NEXT tile with a counted
+// s_waitcnt vmcnt(N) that leaves the tile after it in flight, then all waves meet at ONE raw
+// s_barrier per K tile.  That barrier is both the "tile t+1 has landed for everybody" point (read
+// a staged buffer only after the wait that retires it AND a barrier) and the "everybody is done
+// reading tile t" point (its buffer is re-staged only in the following iteration).
+//
+// The weight fragment is the first MFMA operand, the activation fragment the second, so lane l
+// holds C[m = l & 15][n = 4 (l >> 4) + j]: four consecutive n of a row-major C per accumulator.
+#pragma once
+
+#include "wq_kernels.h"
+
+namespace wq {
+
+template <int BKIND>
+struct Mfma256
+{
+    static constexpr int BM = 256, BN = 256, BK = 64, THREADS = 512, NBUF = 3;
+    static constexpr int A_ROW_BYTES = BK * 2;                              // 128
+    static constexpr int B_ROW_BYTES = BK / 8 * BInfo<BKIND>::kBytesPer8K;  // 32 or 64
+    static constexpr int A_TILE      = BM * A_ROW_BYTES;                    // 32 KiB
+    static constexpr int B_TILE      = BN * B_ROW_BYTES;                    // 8 or 16 KiB
+    static constexpr int STAGE       = A_TILE + B_TILE;
+    static constexpr int LDS_BYTES   = NBUF * STAGE;                        // 120 or 144 KiB
+    static constexpr int A_DMA       = A_TILE / 1024 / 8;                   // LDS-DMA instructions per wave per tile: 4
+    static constexpr int B_DMA       = B_TILE / 1024 / 8;                   // 1 or 2
+    static constexpr int DMA_PER_TILE = A_DMA + B_DMA;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// (w & mask) | magic in one VALU instruction; mask and magic live in registers.
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask, uint32_t magic)
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(mask), "v"(magic));
+    return r;
+}
+
+struct I4Consts
+{
+    uint32_t mask_lo, mask_hi, magic;
+    h2_t k1032, k16th, km72;
+    __device__ __forceinline__ void init()
+    {
+        mask_lo = 0x000F000Fu;
+        mask_hi = 0x00F000F0u;
+        magic   = 0x64006400u;
+        // keep the three words in VGPRs so v_and_or_b32 can take them (one literal at most otherwise)
+        asm volatile("" : "+v"(mask_lo), "+v"(mask_hi), "+v"(magic));
+        k1032 = h2_t{(_Float16)1032.0f, (_Float16)1032.0f};
+        k16th = h2_t{(_Float16)0.0625f, (_Float16)0.0625f};
+        km72  = h2_t{(_Float16)-72.0f, (_Float16)-72.0f};
+    }
+};
+
+// fp16 x packed int4, 13 VALU per 8 weights (see dequant8 in wq_device.h for the arithmetic).
+__device__ __forceinline__ u4_t dequant8_i4_f16(const ScaleReg<A_F16>& sc, const I4Consts& c, uint32_t w)
+{
+    const uint32_t w8 = w >> 8;
+    const h2_t t0     = as_h2(and_or(w, c.mask_lo, c.magic));
+    const h2_t t1     = as_h2(and_or(w, c.mask_hi, c.magic));
+    const h2_t t2     = as_h2(and_or(w8, c.mask_lo, c.magic));
+    const h2_t t3     = as_h2(and_or(w8, c.mask_hi, c.magic));
+    u4_t r;
+    r[0] = as_u32((t0 - c.k1032) * sc.s2);
+    r[1] = as_u32(__builtin_elementwise_fma(t1, c.k16th, c.km72) * sc.s2);
+    r[2] = as_u32((t2 - c.k1032) * sc.s2);
+    r[3] = as_u32(__builtin_elementwise_fma(t3, c.k16th, c.km72) * sc.s2);
+    return r;
+}
+
+template <int AK, int BKIND>
+__global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
+{
+    using T = Mfma256<BKIND>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr   = lane & 15;
+    const int fq   = lane >> 4;
+    const int wm   = wave >> 2; // M half
+    const int wn   = wave & 3;  // N quarter
+
+    int tm, tn;
+    {
+        const int nwg = p.tiles_m * p.tiles_n;
+        tile_coords(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, tm, tn);
+    }
+    const int m0 = tm * T::BM, n0 = tn * T::BN;
+
+    const int kz_begin = p.k_begin + blockIdx.z * p.k_per_z;
+    const int kz_end   = min(p.k_end, kz_begin + p.k_per_z);
+    const int ntiles   = (kz_end - kz_begin) / T::BK;
+
+    ScaleReg<AK> sc[4];
+    {
+        const uint16_t mine = ((const uint16_t*)p.scale)[n0 + wn * 64 + lane];
+#pragma unroll
+        for(int nt = 0; nt < 4; ++nt)
+            sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));
+    }
+    I4Consts i4c;
+    i4c.init();
+
+    // ---- LDS-DMA source addresses (per lane) and destinations (per wave) ---------------------
+    // A: wave-instruction i of wave w moves rows 8 (4 w + i) .. +7; lane -> row lane / 8, 16-byte
+    // position lane % 8, which receives global chunk position ^ (row & 7).
+    const uint8_t* a_src[T::A_DMA];
+#pragma unroll
+    for(int i = 0; i < T::A_DMA; ++i)
+    {
+        const int row   = (wave * T::A_DMA + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        a_src[i] = (const uint8_t*)p.a + ((size_t)(m0 + row) * p.lda + kz_begin) * 2 + chunk * 16;
+    }
+    constexpr int B_CHUNKS         = T::B_ROW_BYTES / 16; // 2 or 4
+    constexpr int B_COLS_PER_INSTR = 64 / B_CHUNKS;       // 32 or 16
+    const uint8_t* b_src[T::B_DMA];
+#pragma unroll
+    for(int i = 0; i < T::B_DMA; ++i)
+    {
+        const int col   = (wave * T::B_DMA + i) * B_COLS_PER_INSTR + lane / B_CHUNKS;
+        const int chunk = (lane % B_CHUNKS) ^ ((col >> 2) & (B_CHUNKS - 1));
+        b_src[i]        = (const uint8_t*)p.b + (size_t)(n0 + col) * p.ldb_bytes +
+                   (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + chunk * 16;
+    }
+
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
+        uint8_t* sa = lds + buf * T::STAGE;
+        uint8_t* sb = sa + T::A_TILE;
+#pragma unroll
+        for(int i = 0; i < T::A_DMA; ++i)
+            glds16(a_src[i] + (size_t)kt * T::A_ROW_BYTES, sa + (wave * T::A_DMA + i) * 1024);
+#pragma unroll
+        for(int i = 0; i < T::B_DMA; ++i)
+            glds16(b_src[i] + (size_t)kt * T::B_ROW_BYTES, sb + (wave * T::B_DMA + i) * 1024);
+    };
+
+    f4_t acc[4][8]; // [nt][mt]
+#pragma unroll
+    for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < 8; ++mt)
+            acc[nt][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS read offsets that do not depend on the buffer
+    int a_off[2];     // for k-step s: byte offset of this lane's 16-byte chunk in row (.. + fr) of m-tile 0
+    const int a_row0 = wm * 128 + fr;
+#pragma unroll
+    for(int s = 0; s < 2; ++s)
+        a_off[s] = a_row0 * 128 + (((4 * s + fq) ^ (a_row0 & 7)) << 4); // (row + 16 mt) & 7 == row & 7
+
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const uint8_t* sa = lds + buf * T::STAGE;
+        const uint8_t* sb = sa + T::A_TILE;
+#pragma unroll
+        for(int s = 0; s < 2; ++s)
+        {
+            u4_t wf[4], af[8];
+#pragma unroll
+            for(int nt = 0; nt < 4; ++nt)
+            {
+                const int col = wn * 64 + nt * 16 + fr;
+                if constexpr(BKIND == B_I4P)
+                {
+                    const int chunk  = s ^ ((col >> 2) & 1);
+                    const uint32_t w = *(const uint32_t*)(sb + col * 32 + chunk * 16 + fq * 4);
+                    if constexpr(AK == A_F16)
+                        wf[nt] = dequant8_i4_f16(sc[nt], i4c, w);
+                    else
+                        wf[nt] = dequant8(sc[nt], w, std::integral_constant<int, B_I4P>{});
+                }
+                else
+                {
+                    const int chunk = (2 * s + (fq >> 1)) ^ ((col >> 2) & 3);
+                    const u2_t w    = *(const u2_t*)(sb + col * 64 + chunk * 16 + (fq & 1) * 8);
+                    if constexpr(AK == A_F16)
+                        wf[nt] = dequant8_bytes_f16<BKIND>(sc[nt], w);
+                    else
+                        wf[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], w);
+                }
+            }
+#pragma unroll
+            for(int mt = 0; mt < 8; ++mt)
+                af[mt] = *(const u4_t*)(sa + a_off[s] + mt * 16 * 128);
+#pragma unroll
+            for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for(int mt = 0; mt < 8; ++mt)
+                {
+                    if constexpr(AK == A_F16)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            __builtin_bit_cast(h8_t, wf[nt]), __builtin_bit_cast(h8_t, af[mt]),
+                            acc[nt][mt], 0, 0, 0);
+                    else
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf8_t, wf[nt]), __builtin_bit_cast(bf8_t, af[mt]),
+                            acc[nt][mt], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop -----------------------------------------------------------------------------
+    if(ntiles > 0)
+    {
+        stage(0, 0);
+        if(ntiles > 1)
+        {
+            stage(1, 1);
+            wait_vmcnt<T::DMA_PER_TILE>(); // tile 0 landed (this wave's part); tile 1 in flight
+        }
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+
+        int cur = 0; // buffer of tile t
+        for(int t = 0; t < ntiles; ++t)
+        {
+            int nxt2 = cur + 2;
+            nxt2     = nxt2 >= T::NBUF ? nxt2 - T::NBUF : nxt2;
+            if(t + 2 < ntiles)
+                stage(nxt2, t + 2); // overwrites the buffer of tile t-1: every wave passed the last barrier after reading it
+            compute(cur);
+            // tile t+1 must have landed: leave only tile t+2's DMA (if it was issued) in flight
+            if(t + 2 < ntiles)
+                wait_vmcnt<T::DMA_PER_TILE>();
+            else
+                wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = cur + 1 >= T::NBUF ? 0 : cur + 1;
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    tile_epilogue<4, 8>(p, acc, m0 + wm * 128, n0 + wn * 64, fr, fq);
+}
+
+} // namespace wq

@@ -57,6 +57,56 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
     tn                  = r / gsz;
 }
 
+
+// Epilogue of an MFMA tile kernel: NT x MT accumulator fragments per wave; fragment (nt, mt) covers
+// rows m_base + 16 mt + (lane & 15), columns n_base + 16 nt + 4 (lane >> 4) .. +3.  The epilogue
+// kind and output type are resolved once, outside the fully unrolled fragment loops.
+template <int KIND, bool BF16, int NT, int MT>
+__device__ __forceinline__ void tile_epilogue_k(const GemmParams& p, const f4_t (&acc)[NT][MT], int m_base,
+                                                int n_base, int fr, int fq)
+{
+#pragma unroll
+    for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < MT; ++mt)
+            store_c4<KIND, BF16>(p.epi, p.c, p.ldc, acc[nt][mt], m_base + mt * 16 + fr, n_base + nt * 16 + fq * 4);
+}
+
+template <int NT, int MT>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&acc)[NT][MT], int m_base,
+                                              int n_base, int fr, int fq)
+{
+    if(p.partial)
+    {
+        float* slab = (float*)p.c + (size_t)blockIdx.z * p.M * p.ldc;
+#pragma unroll
+        for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for(int mt = 0; mt < MT; ++mt)
+                *(f4_t*)(slab + (size_t)(m_base + mt * 16 + fr) * p.ldc + n_base + nt * 16 + fq * 4) = acc[nt][mt];
+        return;
+    }
+    const bool bf = p.epi.c_dtype == 1;
+    switch(p.epi.kind)
+    {
+    case 1:
+        bf ? tile_epilogue_k<1, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<1, false>(p, acc, m_base, n_base, fr, fq);
+        break;
+    case 2:
+        bf ? tile_epilogue_k<2, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<2, false>(p, acc, m_base, n_base, fr, fq);
+        break;
+    case 3:
+        bf ? tile_epilogue_k<3, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<3, false>(p, acc, m_base, n_base, fr, fq);
+        break;
+    case 4:
+        bf ? tile_epilogue_k<4, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<4, false>(p, acc, m_base, n_base, fr, fq);
+        break;
+    default:
+        bf ? tile_epilogue_k<0, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<0, false>(p, acc, m_base, n_base, fr, fq);
+        break;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 128 x 128 x 64 MFMA kernel
 // ---------------------------------------------------------------------------------------------
@@ -140,7 +190,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
                    (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + chunk * 16;
     }
 
-    auto stage = [&](int buf, int kt) {
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         uint8_t* sa = lds + buf * T::STAGE;
         uint8_t* sb = sa + T::A_TILE;
 #pragma unroll
@@ -158,7 +208,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
         for(int mt = 0; mt < 4; ++mt)
             acc[nt][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const uint8_t* sa = lds + buf * T::STAGE;
         const uint8_t* sb = sa + T::A_TILE;
 #pragma unroll
@@ -225,30 +275,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
-#pragma unroll
-    for(int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for(int mt = 0; mt < 4; ++mt)
-        {
-            const int m = m0 + wm * 64 + mt * 16 + fr;
-            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-            if(p.partial)
-            {
-                float* dst = (float*)p.c + (size_t)blockIdx.z * p.M * p.ldc + (size_t)m * p.ldc + n;
-                *(f4_t*)dst = acc[nt][mt];
-            }
-            else
-            {
-                uint16_t o[4];
-#pragma unroll
-                for(int j = 0; j < 4; ++j)
-                    o[j] = cvt_out16(apply_epilogue(p.epi, acc[nt][mt][j], m, n + j), p.epi.c_dtype);
-                u2_t pk;
-                pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-                pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-                *(u2_t*)((uint16_t*)p.c + (size_t)m * p.ldc + n) = pk;
-            }
-        }
+    tile_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------

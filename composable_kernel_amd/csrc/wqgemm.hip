@@ -10,6 +10,7 @@
 
 #include "wqgemm.h"
 #include "wq_kernels.h"
+#include "wq_gemm_256.h"
 
 namespace {
 
@@ -36,6 +37,7 @@ enum Route
 {
     ROUTE_NONE = 0,
     ROUTE_MFMA128,
+    ROUTE_MFMA256,
     ROUTE_GENERIC
 };
 
@@ -63,8 +65,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags != 0)
-        return fail(WQ_ERR_INVALID, "flags must be 0");
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256))
+        return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
     if(p->a_layout != WQ_ROW_MAJOR && p->a_layout != WQ_COL_MAJOR)
@@ -160,6 +162,17 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
                        ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
     plan.route = tiled ? ROUTE_MFMA128 : ROUTE_GENERIC;
+    if(tiled && p->M % 256 == 0 && p->N % 256 == 0 && !(p->flags & WQ_FLAG_TILE_128))
+    {
+        // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
+        const long wgs = (long)(p->M / 256) * (p->N / 256) * plan.k_batch;
+        if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256))
+            plan.route = ROUTE_MFMA256;
+    }
+    if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)
+        return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs M and N to be multiples of 256 and tile-aligned operands");
+    if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_MFMA128)
+        return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_128 needs M and N to be multiples of 128 and tile-aligned operands");
     return WQ_OK;
 }
 
@@ -180,12 +193,31 @@ void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
 }
 
+template <int AK, int BKIND>
+int launch_mfma256(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
+{
+    // more than 64 KiB of dynamic LDS must be opted into once per device
+    static bool opted_in[64] = {};
+    int dev                  = 0;
+    WQ_HIP(hipGetDevice(&dev));
+    constexpr int lds_bytes = wq::Mfma256<BKIND>::LDS_BYTES;
+    if(dev >= 0 && dev < 64 && !opted_in[dev])
+    {
+        WQ_HIP(hipFuncSetAttribute((const void*)wq::wq_gemm_mfma_256<AK, BKIND>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        opted_in[dev] = true;
+    }
+    hipLaunchKernelGGL((wq::wq_gemm_mfma_256<AK, BKIND>), grid, dim3(512), lds_bytes, s, gp);
+    return WQ_OK;
+}
+
 int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipStream_t s)
 {
     void* out  = plan.partial && !plan.to_c ? workspace : p->c;
     const int ld_out = plan.partial && !plan.to_c ? p->N : p->ldc;
-    if(plan.route == ROUTE_MFMA128)
+    if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
     {
+        const int tile = plan.route == ROUTE_MFMA256 ? 256 : 128;
         wq::GemmParams gp;
         gp.a         = p->a;
         gp.b         = p->b;
@@ -201,11 +233,25 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_end     = plan.k_end;
         gp.k_per_z   = plan.k_per_z;
         gp.partial   = plan.partial ? 1 : 0;
-        gp.tiles_m   = p->M / 128;
-        gp.tiles_n   = p->N / 128;
+        gp.tiles_m   = p->M / tile;
+        gp.tiles_n   = p->N / tile;
         gp.epi       = epilogue_of(p);
         const dim3 grid(gp.tiles_m * gp.tiles_n, 1, plan.k_batch);
-        if(plan.ak == wq::A_F16)
+        if(plan.route == ROUTE_MFMA256)
+        {
+            int rc;
+            if(plan.ak == wq::A_F16)
+                rc = plan.bk == wq::B_I4P   ? launch_mfma256<wq::A_F16, wq::B_I4P>(gp, grid, s)
+                     : plan.bk == wq::B_U8O ? launch_mfma256<wq::A_F16, wq::B_U8O>(gp, grid, s)
+                                            : launch_mfma256<wq::A_F16, wq::B_I8>(gp, grid, s);
+            else
+                rc = plan.bk == wq::B_I4P   ? launch_mfma256<wq::A_BF16, wq::B_I4P>(gp, grid, s)
+                     : plan.bk == wq::B_U8O ? launch_mfma256<wq::A_BF16, wq::B_U8O>(gp, grid, s)
+                                            : launch_mfma256<wq::A_BF16, wq::B_I8>(gp, grid, s);
+            if(rc != WQ_OK)
+                return rc;
+        }
+        else if(plan.ak == wq::A_F16)
         {
             if(plan.bk == wq::B_I4P)
                 launch_mfma128<wq::A_F16, wq::B_I4P>(gp, grid, s);
@@ -387,11 +433,12 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
         snprintf(buf, n, "DeviceWqGemm_gfx950<unsupported>");
         return WQ_ERR_UNSUPPORTED;
     }
-    if(plan.route == ROUTE_MFMA128)
+    if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
         snprintf(buf, n,
-                 "DeviceFpAintBGemm_Mfma_gfx950<256, 128, 128, 64, 16x16x32, %s, %s, %s, LdsDma, "
+                 "DeviceFpAintBGemm_Mfma_gfx950<%s, 64, 16x16x32, %s, %s, %s, LdsDma, "
                  "DequantInRegister, KBatch%d>",
-                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
+                 plan.route == ROUTE_MFMA256 ? "512, 256, 256" : "256, 128, 128", dt_name(p->a_dtype),
+                 dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
     else
         snprintf(buf, n, "DeviceWqGemm_Generic_gfx950<256, 16, 16, %s, %s, %s, KBatch%d>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
@@ -406,7 +453,10 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
     const int rc = make_plan(p, plan);
     if(rc != WQ_OK)
         return rc;
-    snprintf(buf, n, "%s", plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128" : "wq_gemm_generic");
+    snprintf(buf, n, "%s",
+             plan.route == ROUTE_MFMA256   ? "wq_gemm_mfma_256"
+             : plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128"
+                                           : "wq_gemm_generic");
     return WQ_OK;
 }
 

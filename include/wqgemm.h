@@ -58,6 +58,10 @@ typedef enum wq_epilogue
     WQ_EPI_ACT_MUL_CLAMP              = 5  /* quantization_operation.hpp:24-66; requant_scale, int8 out    */
 } wq_epilogue;
 
+/* wqgemm_problem.flags */
+#define WQ_FLAG_TILE_128 1 /* force the 128 x 128 x 64 MFMA kernel */
+#define WQ_FLAG_TILE_256 2 /* force the 256 x 256 x 64 MFMA kernel */
+
 /* One GEMM problem: C[M,N] = epilogue( sum_k A[m,k] * dequant(B[k,n], scale[n]) ).
  * Mirrors what Argument objects capture in the reference
  * (include/ck/tensor_operation/gpu/device/impl/device_fpAintB_gemm_wmma.hpp:343-417):
@@ -86,7 +90,7 @@ typedef struct wqgemm_problem
      * multi-GPU split-K.  Both zero = the whole K range. */
     int32_t k_batch;
     int32_t k_begin, k_end;
-    int32_t flags; /* reserved, must be 0 */
+    int32_t flags; /* 0, or one of WQ_FLAG_TILE_* to pin the tile shape (testing / tuning) */
 } wqgemm_problem;
 
 /* Library version string, e.g. "wqgemm 0.1 (gfx950)". */

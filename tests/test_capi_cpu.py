@@ -31,8 +31,13 @@ def _problem(**kw):
 def test_is_supported_and_routes():
     p = _problem()
     assert capi.is_supported(p)
-    assert capi.kernel_name(p) == "wq_gemm_mfma_128"
+    assert capi.kernel_name(p) == "wq_gemm_mfma_256"      # 256 tiles: one 256 x 256 workgroup per CU
     assert "DeviceFpAintBGemm_Mfma_gfx950" in capi.type_string(p)
+    assert capi.kernel_name(_problem(flags=capi.FLAG_TILE_128)) == "wq_gemm_mfma_128"
+    assert capi.kernel_name(_problem(M=512, N=512)) == "wq_gemm_mfma_128"   # too few 256-tiles to fill the chip
+    assert capi.kernel_name(_problem(M=512, N=512, flags=capi.FLAG_TILE_256)) == "wq_gemm_mfma_256"
+    assert not capi.is_supported(_problem(M=384, N=512, flags=capi.FLAG_TILE_256))
+    assert not capi.is_supported(_problem(flags=64))
     # ragged shapes fall back to the generic HIP kernel (still supported)
     p = _problem(M=33, N=17, K=72, lda=80, ldb=88, ldc=24)
     assert capi.is_supported(p) and capi.kernel_name(p) == "wq_gemm_generic"

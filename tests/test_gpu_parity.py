@@ -18,6 +18,7 @@ from gpu_util import (bf16_bits, bits_to_f32, check_err, dev, f16_bits, host_u16
 pytestmark = pytest.mark.gpu
 
 MFMA = "wq_gemm_mfma_128"
+MFMA256 = "wq_gemm_mfma_256"
 GENERIC = "wq_gemm_generic"
 
 
@@ -261,7 +262,7 @@ def test_full_size_c2_properties(port):
     bp = pack_on_device(q, K, N)
     a = f16_bits(rng.uniform(-1, 1, (M, K)))
     s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
-    got = run_fpaintb(a, bp, s, M, N, K, expect_kernel=MFMA)
+    got = run_fpaintb(a, bp, s, M, N, K, expect_kernel=MFMA256)
     rows = slice(1000, 1032)
     exp = port.fpAintB_gemm_f16(np.ascontiguousarray(a[rows]), q, s, 32, N, K, K, K, N).reshape(32, N)
     check_err(bits_to_f32(got[rows], capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
@@ -273,9 +274,75 @@ def test_full_size_c2_properties(port):
     # integer-valued inputs at full size: the MFMA kernel must equal the generic kernel bit for bit
     ai = f16_bits(np.round(rng.uniform(-1, 1, (M, K))))
     si = f16_bits(rng.integers(1, 3, N).astype(np.float32))
-    got = run_fpaintb(ai, bp, si, M, N, K, expect_kernel=MFMA)
+    got = run_fpaintb(ai, bp, si, M, N, K, expect_kernel=MFMA256)
     gen = run_fpaintb(np.ascontiguousarray(ai[512:512 + 96]), bp, si, 96, N, K, expect_kernel=GENERIC)
+    # ... and the 128-tile kernel on the same full-size problem
+    got128 = run_fpaintb(ai, bp, si, M, N, K, flags=capi.FLAG_TILE_128, expect_kernel=MFMA)
+    np.testing.assert_array_equal(got128, got)
     np.testing.assert_array_equal(got[512:512 + 96], gen)
     # linearity in the scale: doubling every scale doubles the output exactly (power of two)
     got2 = run_fpaintb(ai, bp, f16_bits(2 * si.view(np.float16).astype(np.float32)), M, N, K)
     np.testing.assert_array_equal(bits_to_f32(got2, capi.F16), 2 * bits_to_f32(got, capi.F16))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 256, 1024), (768, 1024, 4096)])
+def test_tile256_kernel_fp16_int4(port, M, N, K):
+    """The 256 x 256 kernel (3-buffer LDS ring, counted waits) forced at small and ragged tile counts:
+    1, 2, 3 and many K tiles exercise the prologue / steady state / drain of the ring."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    a = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+    s = f16_bits(rng.integers(1, 4, N).astype(np.float32))
+    got = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
+    if M * N * K <= 256 * 512 * 1024:
+        exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    else:
+        exp = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_128, expect_kernel=MFMA)
+    np.testing.assert_array_equal(got, exp)
+    a = f16_bits(rng.uniform(-1, 1, (M, K)))
+    s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    got = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
+    if M * N * K <= 256 * 512 * 1024:
+        exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    else:
+        exp = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_128, expect_kernel=MFMA)
+    check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("a_dtype,b_dtype", [(capi.F16, capi.I8), (capi.F16, capi.U8_OFFSET), (capi.BF16, capi.I8),
+                                             (capi.BF16, capi.I4_PACKED)])
+def test_tile256_kernel_other_formats(port, a_dtype, b_dtype):
+    rng = np.random.default_rng(a_dtype * 10 + b_dtype)
+    M, N, K = 256, 512, 320
+    lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
+    q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+    if b_dtype == capi.I4_PACKED:
+        b = pack_on_device(q, K, N)
+    elif b_dtype == capi.U8_OFFSET:
+        b = (q.astype(np.int16) + 128).astype(np.uint8)
+    else:
+        b = q
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+    a = cvt(np.round(rng.uniform(-1, 1, (M, K))))
+    s = cvt(rng.integers(1, 3, N).astype(np.float32))
+    got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, flags=capi.FLAG_TILE_256,
+                      expect_kernel=MFMA256)
+    if a_dtype == capi.F16:
+        exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    else:
+        exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_tile256_splitk_and_slices(port):
+    rng = np.random.default_rng(77)
+    M, N, K = 256, 256, 1024
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    a = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+    s = f16_bits(rng.integers(1, 3, N).astype(np.float32))
+    exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    for kb in (2, 3, 5):
+        got = run_fpaintb(a, bp, s, M, N, K, k_batch=kb, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
+        np.testing.assert_array_equal(got, exp)
