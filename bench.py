@@ -70,11 +70,11 @@ def cpu_baseline_leg(a, q, s, c_gpu, M, N, K, budget_s=12.0):
     a_h = a.cpu().numpy().view(np.uint16)
     q_h = q.cpu().numpy()
     s_h = s.cpu().numpy().view(np.uint16)
-    # calibrate on 4 rows, then size the block for ~budget_s (at most 128 rows)
+    # calibrate on 4 rows, then size the block for ~budget_s (at most 1024 rows)
     t0 = time.perf_counter()
     port.fpAintB_gemm_f16(np.ascontiguousarray(a_h[:4]), q_h, s_h, 4, N, K, K, K, N, nthreads=cores)
     t_cal = time.perf_counter() - t0
-    rows = int(max(8, min(128, (budget_s / max(t_cal, 1e-6)) * 4)))
+    rows = int(max(8, min(1024, (budget_s / max(t_cal, 1e-6)) * 4)))
     rows -= rows % 8
     t0 = time.perf_counter()
     ref = port.fpAintB_gemm_f16(np.ascontiguousarray(a_h[:rows]), q_h, s_h, rows, N, K, K, K, N, nthreads=cores)
@@ -104,7 +104,9 @@ def run_single(args):
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
-    for _ in range(args.warmup):
+    # untimed warm-up: the W requested steps plus enough launches (~0.2 s) for the clocks to settle
+    ramp = max(0, args.ramp_launches)
+    for _ in range(args.warmup + ramp):
         capi.launch(p, None, sp)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -127,6 +129,7 @@ def run_single(args):
         "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
+        "warmup_extra_untimed_launches": ramp,
         "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
@@ -255,11 +258,13 @@ def run_splitk(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the baseline")
     ap.add_argument("--splitk-k", type=int, default=65536)
+    ap.add_argument("--ramp-launches", type=int, default=1500,
+                    help="extra untimed launches before the timed region so the GPU clocks have settled")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (run it through gpurun)")

@@ -83,7 +83,7 @@ __device__ __forceinline__ u4_t dequant8_i4_f16(const ScaleReg<A_F16>& sc, const
     return r;
 }
 
-template <int AK, int BKIND>
+template <int AK, int BKIND, bool PINGPONG>
 __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
 {
     using T = Mfma256<BKIND>;
@@ -165,54 +165,54 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
     for(int s = 0; s < 2; ++s)
         a_off[s] = a_row0 * 128 + (((4 * s + fq) ^ (a_row0 & 7)) << 4); // (row + 16 mt) & 7 == row & 7
 
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    u4_t wf[4], af[8]; // operand fragments of one 32-deep k-step
+
+    // L section: fetch this wave's fragments of k-step s from LDS and dequantise the weights.
+    auto load_frags = [&](int buf, int s) __attribute__((always_inline)) {
         const uint8_t* sa = lds + buf * T::STAGE;
         const uint8_t* sb = sa + T::A_TILE;
 #pragma unroll
-        for(int s = 0; s < 2; ++s)
-        {
-            u4_t wf[4], af[8];
+        for(int mt = 0; mt < 8; ++mt)
+            af[mt] = *(const u4_t*)(sa + a_off[s] + mt * 16 * 128);
 #pragma unroll
-            for(int nt = 0; nt < 4; ++nt)
+        for(int nt = 0; nt < 4; ++nt)
+        {
+            const int col = wn * 64 + nt * 16 + fr;
+            if constexpr(BKIND == B_I4P)
             {
-                const int col = wn * 64 + nt * 16 + fr;
-                if constexpr(BKIND == B_I4P)
-                {
-                    const int chunk  = s ^ ((col >> 2) & 1);
-                    const uint32_t w = *(const uint32_t*)(sb + col * 32 + chunk * 16 + fq * 4);
-                    if constexpr(AK == A_F16)
-                        wf[nt] = dequant8_i4_f16(sc[nt], i4c, w);
-                    else
-                        wf[nt] = dequant8(sc[nt], w, std::integral_constant<int, B_I4P>{});
-                }
+                const int chunk  = s ^ ((col >> 2) & 1);
+                const uint32_t w = *(const uint32_t*)(sb + col * 32 + chunk * 16 + fq * 4);
+                if constexpr(AK == A_F16)
+                    wf[nt] = dequant8_i4_f16(sc[nt], i4c, w);
                 else
-                {
-                    const int chunk = (2 * s + (fq >> 1)) ^ ((col >> 2) & 3);
-                    const u2_t w    = *(const u2_t*)(sb + col * 64 + chunk * 16 + (fq & 1) * 8);
-                    if constexpr(AK == A_F16)
-                        wf[nt] = dequant8_bytes_f16<BKIND>(sc[nt], w);
-                    else
-                        wf[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], w);
-                }
+                    wf[nt] = dequant8(sc[nt], w, std::integral_constant<int, B_I4P>{});
             }
+            else
+            {
+                const int chunk = (2 * s + (fq >> 1)) ^ ((col >> 2) & 3);
+                const u2_t w    = *(const u2_t*)(sb + col * 64 + chunk * 16 + (fq & 1) * 8);
+                if constexpr(AK == A_F16)
+                    wf[nt] = dequant8_bytes_f16<BKIND>(sc[nt], w);
+                else
+                    wf[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], w);
+            }
+        }
+    };
+
+    // M section: 32 MFMAs on the fragments in registers.
+    auto mfma_frags = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for(int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for(int mt = 0; mt < 8; ++mt)
-                af[mt] = *(const u4_t*)(sa + a_off[s] + mt * 16 * 128);
-#pragma unroll
-            for(int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for(int mt = 0; mt < 8; ++mt)
-                {
-                    if constexpr(AK == A_F16)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                            __builtin_bit_cast(h8_t, wf[nt]), __builtin_bit_cast(h8_t, af[mt]),
-                            acc[nt][mt], 0, 0, 0);
-                    else
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf8_t, wf[nt]), __builtin_bit_cast(bf8_t, af[mt]),
-                            acc[nt][mt], 0, 0, 0);
-                }
-        }
+            {
+                if constexpr(AK == A_F16)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        __builtin_bit_cast(h8_t, wf[nt]), __builtin_bit_cast(h8_t, af[mt]), acc[nt][mt], 0, 0, 0);
+                else
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf8_t, wf[nt]), __builtin_bit_cast(bf8_t, af[mt]), acc[nt][mt], 0, 0, 0);
+            }
     };
 
     // ---- main loop -----------------------------------------------------------------------------
@@ -228,22 +228,82 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
 
-        int cur = 0; // buffer of tile t
-        for(int t = 0; t < ntiles; ++t)
+        if constexpr(!PINGPONG)
         {
-            int nxt2 = cur + 2;
-            nxt2     = nxt2 >= T::NBUF ? nxt2 - T::NBUF : nxt2;
-            if(t + 2 < ntiles)
-                stage(nxt2, t + 2); // overwrites the buffer of tile t-1: every wave passed the last barrier after reading it
-            compute(cur);
-            // tile t+1 must have landed: leave only tile t+2's DMA (if it was issued) in flight
-            if(t + 2 < ntiles)
-                wait_vmcnt<T::DMA_PER_TILE>();
-            else
-                wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur = cur + 1 >= T::NBUF ? 0 : cur + 1;
+            int cur = 0; // buffer of tile t
+            for(int t = 0; t < ntiles; ++t)
+            {
+                int nxt2 = cur + 2;
+                nxt2     = nxt2 >= T::NBUF ? nxt2 - T::NBUF : nxt2;
+                if(t + 2 < ntiles)
+                    stage(nxt2, t + 2); // overwrites the buffer of tile t-1: every wave passed the last barrier after reading it
+                load_frags(cur, 0);
+                mfma_frags();
+                load_frags(cur, 1);
+                mfma_frags();
+                // tile t+1 must have landed: leave only tile t+2's DMA (if it was issued) in flight
+                if(t + 2 < ntiles)
+                    wait_vmcnt<T::DMA_PER_TILE>();
+                else
+                    wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                cur = cur + 1 >= T::NBUF ? 0 : cur + 1;
+            }
+        }
+        else
+        {
+            // Ping-pong: the second wave of every SIMD (waves 4..7) runs one barrier behind the first, so
+            // between two consecutive barriers one wave of a SIMD issues its 32 MFMAs while its partner
+            // reads LDS and dequantises (VALU) for its next MFMA section.  Sections per K tile and wave:
+            //   L0 [stage t+2; fragments of k-step 0]  b  M0  b  L1 [fragments of k-step 1; wait for tile
+            //   t+1's DMA]  b  M1  b.   Every wave executes the same number of barriers (the late group
+            // one extra before the loop, the early group one extra after it).
+            //   RAW: a wave waits for its own DMA of tile t+1 at the end of L1(t); the first read of tile
+            //        t+1 (early group's L0(t+1)) comes after at least one more barrier that every wave
+            //        reaches only behind that wait.
+            //   WAR: the buffer of tile t-1 is re-staged in L0(t); the late group's last reads of it (its
+            //        L1(t-1)) are retired by the lgkmcnt(0) in front of the barrier that the early group
+            //        must pass before it starts L0(t).
+            auto section_end = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if(wm == 1)
+                __builtin_amdgcn_s_barrier();
+            int cur = 0;
+            for(int t = 0; t < ntiles; ++t)
+            {
+                int nxt2 = cur + 2;
+                nxt2     = nxt2 >= T::NBUF ? nxt2 - T::NBUF : nxt2;
+                // L0
+                if(t + 2 < ntiles)
+                    stage(nxt2, t + 2);
+                load_frags(cur, 0);
+                section_end();
+                // M0
+                __builtin_amdgcn_s_setprio(1);
+                mfma_frags();
+                __builtin_amdgcn_s_setprio(0);
+                section_end();
+                // L1
+                load_frags(cur, 1);
+                if(t + 2 < ntiles)
+                    wait_vmcnt<T::DMA_PER_TILE>();
+                else
+                    wait_vmcnt<0>();
+                section_end();
+                // M1
+                __builtin_amdgcn_s_setprio(1);
+                mfma_frags();
+                __builtin_amdgcn_s_setprio(0);
+                section_end();
+                cur = cur + 1 >= T::NBUF ? 0 : cur + 1;
+            }
+            if(wm == 0)
+                __builtin_amdgcn_s_barrier();
         }
     }
 
