@@ -1,9 +1,13 @@
 // 256 x 256 x 64 MFMA kernel of the weight-quantized GEMM engine (gfx950).
 //
 // One 512-thread workgroup (8 waves = 2 per SIMD) per 256 x 256 tile of C, one workgroup per CU.
-// Waves form a 2 (M) x 4 (N) grid; wave (wm, wn) owns rows [128 wm, +128) x columns [64 wn, +64):
-// 8 x 4 accumulator tiles of v_mfma_f32_16x16x32.  SIMD partners (waves w and w + 4) share the
-// weight columns and differ in the M half.
+// Waves form a WM (M) x 8/WM (N) grid:
+//   WM = 2: wave (w >> 2, w & 3) owns 128 rows x 64 columns (8 x 4 accumulator tiles of
+//           v_mfma_f32_16x16x32); SIMD partners (waves w, w + 4) share their weight columns, so every
+//           weight is dequantised twice per workgroup;
+//   WM = 1: wave w owns all 256 rows x 32 columns (16 x 2 accumulator tiles): every weight is
+//           dequantised exactly once per workgroup (half the VALU work per MFMA) at the price of
+//           twice the activation-fragment LDS reads.
 //
 // Staging: A (256 rows x 128 B) and the packed weights (256 columns x 32 or 64 B) of one K tile
 // are moved HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of NBUF = 3 buffers, two K
@@ -83,18 +87,26 @@ __device__ __forceinline__ u4_t dequant8_i4_f16(const ScaleReg<A_F16>& sc, const
     return r;
 }
 
-template <int AK, int BKIND, bool PINGPONG>
+// SCHED: 0 lockstep (one barrier per K tile), 1 ping-pong with the DMA issued in the L0 section,
+//        2 ping-pong with the DMA issued between the MFMAs of the M1 section.
+template <int AK, int BKIND, int WM, int SCHED>
 __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
 {
     using T = Mfma256<BKIND>;
+    constexpr int WN = 8 / WM;        // waves along N
+    constexpr int MT = 256 / WM / 16; // accumulator tiles along M per wave: 8 or 16
+    constexpr int NT = 256 / WN / 16; // accumulator tiles along N per wave: 4 or 2
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr   = lane & 15;
-    const int fq   = lane >> 4;
-    const int wm   = wave >> 2; // M half
-    const int wn   = wave & 3;  // N quarter
+    const int lane  = threadIdx.x & 63;
+    const int wave  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr    = lane & 15;
+    const int fq    = lane >> 4;
+    const int wm    = WM == 2 ? wave >> 2 : 0;
+    const int wn    = WM == 2 ? wave & 3 : wave;
+    const int late  = wave >> 2; // second wave of its SIMD: runs one barrier behind in the ping-pong schedules
+    const int row_w = wm * (MT * 16);
+    const int col_w = wn * (NT * 16);
 
     int tm, tn;
     {
@@ -107,11 +119,13 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
     const int kz_end   = min(p.k_end, kz_begin + p.k_per_z);
     const int ntiles   = (kz_end - kz_begin) / T::BK;
 
-    ScaleReg<AK> sc[4];
+    // per-channel scales: one coalesced load per wave, then a cross-lane broadcast (lane l needs
+    // the scale of column 16 nt + (l & 15) of the wave's NT * 16 columns)
+    ScaleReg<AK> sc[NT];
     {
-        const uint16_t mine = ((const uint16_t*)p.scale)[n0 + wn * 64 + lane];
+        const uint16_t mine = ((const uint16_t*)p.scale)[n0 + col_w + (lane & (NT * 16 - 1))];
 #pragma unroll
-        for(int nt = 0; nt < 4; ++nt)
+        for(int nt = 0; nt < NT; ++nt)
             sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));
     }
     I4Consts i4c;
@@ -151,60 +165,67 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
             glds16(b_src[i] + (size_t)kt * T::B_ROW_BYTES, sb + (wave * T::B_DMA + i) * 1024);
     };
 
-    f4_t acc[4][8]; // [nt][mt]
+    f4_t acc[NT][MT];
 #pragma unroll
-    for(int nt = 0; nt < 4; ++nt)
+    for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for(int mt = 0; mt < 8; ++mt)
+        for(int mt = 0; mt < MT; ++mt)
             acc[nt][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS read offsets that do not depend on the buffer
-    int a_off[2];     // for k-step s: byte offset of this lane's 16-byte chunk in row (.. + fr) of m-tile 0
-    const int a_row0 = wm * 128 + fr;
+    int a_off[2]; // k-step s: byte offset of this lane's 16-byte chunk in row (row_w + fr) of m-tile 0
+    const int a_row0 = row_w + fr;
 #pragma unroll
     for(int s = 0; s < 2; ++s)
         a_off[s] = a_row0 * 128 + (((4 * s + fq) ^ (a_row0 & 7)) << 4); // (row + 16 mt) & 7 == row & 7
 
-    u4_t wf[4], af[8]; // operand fragments of one 32-deep k-step
+    u4_t wf[NT], af[MT]; // operand fragments of one 32-deep k-step
 
     // L section: fetch this wave's fragments of k-step s from LDS and dequantise the weights.
     auto load_frags = [&](int buf, int s) __attribute__((always_inline)) {
         const uint8_t* sa = lds + buf * T::STAGE;
         const uint8_t* sb = sa + T::A_TILE;
+        uint32_t raw4[NT];
+        u2_t raw8[NT];
 #pragma unroll
-        for(int mt = 0; mt < 8; ++mt)
+        for(int nt = 0; nt < NT; ++nt)
+        {
+            const int col = col_w + nt * 16 + fr;
+            if constexpr(BKIND == B_I4P)
+                raw4[nt] = *(const uint32_t*)(sb + col * 32 + ((s ^ ((col >> 2) & 1)) << 4) + fq * 4);
+            else
+                raw8[nt] = *(const u2_t*)(sb + col * 64 + (((2 * s + (fq >> 1)) ^ ((col >> 2) & 3)) << 4) +
+                                          (fq & 1) * 8);
+        }
+#pragma unroll
+        for(int mt = 0; mt < MT; ++mt)
             af[mt] = *(const u4_t*)(sa + a_off[s] + mt * 16 * 128);
 #pragma unroll
-        for(int nt = 0; nt < 4; ++nt)
+        for(int nt = 0; nt < NT; ++nt)
         {
-            const int col = wn * 64 + nt * 16 + fr;
             if constexpr(BKIND == B_I4P)
             {
-                const int chunk  = s ^ ((col >> 2) & 1);
-                const uint32_t w = *(const uint32_t*)(sb + col * 32 + chunk * 16 + fq * 4);
                 if constexpr(AK == A_F16)
-                    wf[nt] = dequant8_i4_f16(sc[nt], i4c, w);
+                    wf[nt] = dequant8_i4_f16(sc[nt], i4c, raw4[nt]);
                 else
-                    wf[nt] = dequant8(sc[nt], w, std::integral_constant<int, B_I4P>{});
+                    wf[nt] = dequant8(sc[nt], raw4[nt], std::integral_constant<int, B_I4P>{});
             }
             else
             {
-                const int chunk = (2 * s + (fq >> 1)) ^ ((col >> 2) & 3);
-                const u2_t w    = *(const u2_t*)(sb + col * 64 + chunk * 16 + (fq & 1) * 8);
                 if constexpr(AK == A_F16)
-                    wf[nt] = dequant8_bytes_f16<BKIND>(sc[nt], w);
+                    wf[nt] = dequant8_bytes_f16<BKIND>(sc[nt], raw8[nt]);
                 else
-                    wf[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], w);
+                    wf[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], raw8[nt]);
             }
         }
     };
 
-    // M section: 32 MFMAs on the fragments in registers.
-    auto mfma_frags = [&]() __attribute__((always_inline)) {
+    // M section: MFMAs on the fragments in registers, accumulator tiles [mt_begin, mt_end).
+    auto mfma_frags = [&](auto mt_begin, auto mt_end) __attribute__((always_inline)) {
 #pragma unroll
-        for(int nt = 0; nt < 4; ++nt)
+        for(int mt = mt_begin; mt < mt_end; ++mt)
 #pragma unroll
-            for(int mt = 0; mt < 8; ++mt)
+            for(int nt = 0; nt < NT; ++nt)
             {
                 if constexpr(AK == A_F16)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
@@ -214,6 +235,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                         __builtin_bit_cast(bf8_t, wf[nt]), __builtin_bit_cast(bf8_t, af[mt]), acc[nt][mt], 0, 0, 0);
             }
     };
+    constexpr std::integral_constant<int, 0> kMt0{};
+    constexpr std::integral_constant<int, MT / 2> kMtHalf{};
+    constexpr std::integral_constant<int, MT> kMtEnd{};
 
     // ---- main loop -----------------------------------------------------------------------------
     if(ntiles > 0)
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
 
-        if constexpr(!PINGPONG)
+        if constexpr(SCHED == 0)
         {
             int cur = 0; // buffer of tile t
             for(int t = 0; t < ntiles; ++t)
@@ -238,9 +262,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                 if(t + 2 < ntiles)
                     stage(nxt2, t + 2); // overwrites the buffer of tile t-1: every wave passed the last barrier after reading it
                 load_frags(cur, 0);
-                mfma_frags();
+                mfma_frags(kMt0, kMtEnd);
                 load_frags(cur, 1);
-                mfma_frags();
+                mfma_frags(kMt0, kMtEnd);
                 // tile t+1 must have landed: leave only tile t+2's DMA (if it was issued) in flight
                 if(t + 2 < ntiles)
                     wait_vmcnt<T::DMA_PER_TILE>();
@@ -254,24 +278,25 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
         else
         {
             // Ping-pong: the second wave of every SIMD (waves 4..7) runs one barrier behind the first, so
-            // between two consecutive barriers one wave of a SIMD issues its 32 MFMAs while its partner
-            // reads LDS and dequantises (VALU) for its next MFMA section.  Sections per K tile and wave:
-            //   L0 [stage t+2; fragments of k-step 0]  b  M0  b  L1 [fragments of k-step 1; wait for tile
-            //   t+1's DMA]  b  M1  b.   Every wave executes the same number of barriers (the late group
-            // one extra before the loop, the early group one extra after it).
+            // between two consecutive barriers one wave of a SIMD issues its MFMAs while its partner reads
+            // LDS and dequantises (VALU) for its next MFMA section.  Sections per K tile and wave:
+            //   L0 [fragments of k-step 0]  b  M0  b  L1 [fragments of k-step 1; wait for tile t+1's DMA]
+            //   b  M1  b,   with the DMA of tile t+2 issued in L0 (SCHED 1) or inside M1 (SCHED 2).
+            // Every wave executes the same number of barriers (the late group one extra before the loop,
+            // the early group one extra after it).
             //   RAW: a wave waits for its own DMA of tile t+1 at the end of L1(t); the first read of tile
             //        t+1 (early group's L0(t+1)) comes after at least one more barrier that every wave
             //        reaches only behind that wait.
-            //   WAR: the buffer of tile t-1 is re-staged in L0(t); the late group's last reads of it (its
-            //        L1(t-1)) are retired by the lgkmcnt(0) in front of the barrier that the early group
-            //        must pass before it starts L0(t).
+            //   WAR: the buffer of tile t-1 is re-staged no earlier than L0(t) of the early group; the late
+            //        group's last reads of it (its L1(t-1)) are retired by the lgkmcnt(0) in front of the
+            //        barrier that the early group must pass before it starts L0(t).
             auto section_end = [&]() __attribute__((always_inline)) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             };
-            if(wm == 1)
+            if(late)
                 __builtin_amdgcn_s_barrier();
             int cur = 0;
             for(int t = 0; t < ntiles; ++t)
@@ -279,36 +304,52 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                 int nxt2 = cur + 2;
                 nxt2     = nxt2 >= T::NBUF ? nxt2 - T::NBUF : nxt2;
                 // L0
-                if(t + 2 < ntiles)
-                    stage(nxt2, t + 2);
+                if constexpr(SCHED == 1)
+                    if(t + 2 < ntiles)
+                        stage(nxt2, t + 2);
                 load_frags(cur, 0);
                 section_end();
                 // M0
                 __builtin_amdgcn_s_setprio(1);
-                mfma_frags();
+                mfma_frags(kMt0, kMtEnd);
                 __builtin_amdgcn_s_setprio(0);
                 section_end();
                 // L1
                 load_frags(cur, 1);
-                if(t + 2 < ntiles)
-                    wait_vmcnt<T::DMA_PER_TILE>();
+                if constexpr(SCHED == 1)
+                {
+                    if(t + 2 < ntiles)
+                        wait_vmcnt<T::DMA_PER_TILE>();
+                    else
+                        wait_vmcnt<0>();
+                }
                 else
-                    wait_vmcnt<0>();
+                    wait_vmcnt<0>(); // only tile t+1's DMA (issued in M1(t-1) or the prologue) is outstanding
                 section_end();
                 // M1
                 __builtin_amdgcn_s_setprio(1);
-                mfma_frags();
+                if constexpr(SCHED == 2)
+                {
+                    mfma_frags(kMt0, kMtHalf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if(t + 2 < ntiles)
+                        stage(nxt2, t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_frags(kMtHalf, kMtEnd);
+                }
+                else
+                    mfma_frags(kMt0, kMtEnd);
                 __builtin_amdgcn_s_setprio(0);
                 section_end();
                 cur = cur + 1 >= T::NBUF ? 0 : cur + 1;
             }
-            if(wm == 0)
+            if(!late)
                 __builtin_amdgcn_s_barrier();
         }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
-    tile_epilogue<4, 8>(p, acc, m0 + wm * 128, n0 + wn * 64, fr, fq);
+    tile_epilogue<NT, MT>(p, acc, m0 + row_w, n0 + col_w, fr, fq);
 }
 
 } // namespace wq

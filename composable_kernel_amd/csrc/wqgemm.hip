@@ -65,7 +65,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP))
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DMA_IN_L0))
         return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
@@ -193,8 +193,8 @@ void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
 }
 
-template <int AK, int BKIND, bool PINGPONG>
-int launch_mfma256_pp(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
+template <int AK, int BKIND, int WM, int SCHED>
+int launch_mfma256_v(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
 {
     // more than 64 KiB of dynamic LDS must be opted into once per device
     static bool opted_in[64] = {};
@@ -203,19 +203,25 @@ int launch_mfma256_pp(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
     constexpr int lds_bytes = wq::Mfma256<BKIND>::LDS_BYTES;
     if(dev >= 0 && dev < 64 && !opted_in[dev])
     {
-        WQ_HIP(hipFuncSetAttribute((const void*)wq::wq_gemm_mfma_256<AK, BKIND, PINGPONG>,
+        WQ_HIP(hipFuncSetAttribute((const void*)wq::wq_gemm_mfma_256<AK, BKIND, WM, SCHED>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         opted_in[dev] = true;
     }
-    hipLaunchKernelGGL((wq::wq_gemm_mfma_256<AK, BKIND, PINGPONG>), grid, dim3(512), lds_bytes, s, gp);
+    hipLaunchKernelGGL((wq::wq_gemm_mfma_256<AK, BKIND, WM, SCHED>), grid, dim3(512), lds_bytes, s, gp);
     return WQ_OK;
 }
 
+// variant = tuning bits of wqgemm_problem.flags: WQ_FLAG_LOCKSTEP, WQ_FLAG_WAVES_2X4, WQ_FLAG_DMA_IN_L0
 template <int AK, int BKIND>
-int launch_mfma256(const wq::GemmParams& gp, dim3 grid, hipStream_t s, bool lockstep)
+int launch_mfma256(const wq::GemmParams& gp, dim3 grid, hipStream_t s, int variant)
 {
-    return lockstep ? launch_mfma256_pp<AK, BKIND, false>(gp, grid, s)
-                    : launch_mfma256_pp<AK, BKIND, true>(gp, grid, s);
+    const bool lockstep = variant & WQ_FLAG_LOCKSTEP, w2x4 = variant & WQ_FLAG_WAVES_2X4,
+               dma_l0 = variant & WQ_FLAG_DMA_IN_L0;
+    if(lockstep)
+        return w2x4 ? launch_mfma256_v<AK, BKIND, 2, 0>(gp, grid, s) : launch_mfma256_v<AK, BKIND, 1, 0>(gp, grid, s);
+    if(dma_l0)
+        return w2x4 ? launch_mfma256_v<AK, BKIND, 2, 1>(gp, grid, s) : launch_mfma256_v<AK, BKIND, 1, 1>(gp, grid, s);
+    return w2x4 ? launch_mfma256_v<AK, BKIND, 2, 2>(gp, grid, s) : launch_mfma256_v<AK, BKIND, 1, 2>(gp, grid, s);
 }
 
 int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipStream_t s)
@@ -246,7 +252,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         const dim3 grid(gp.tiles_m * gp.tiles_n, 1, plan.k_batch);
         if(plan.route == ROUTE_MFMA256)
         {
-            const bool ls = (p->flags & WQ_FLAG_LOCKSTEP) != 0; // tuning A/B switch
+            const int ls = p->flags; // tuning A/B switches
             int rc;
             if(plan.ak == wq::A_F16)
                 rc = plan.bk == wq::B_I4P   ? launch_mfma256<wq::A_F16, wq::B_I4P>(gp, grid, s, ls)

@@ -335,19 +335,23 @@ def test_tile256_kernel_other_formats(port, a_dtype, b_dtype):
     np.testing.assert_array_equal(got, exp)
 
 
-def test_tile256_lockstep_schedule_matches_pingpong(port):
-    """Both wave schedules of the 256-tile kernel (ping-pong default, lockstep) give the same bits."""
+@pytest.mark.parametrize("variant", [capi.FLAG_LOCKSTEP, capi.FLAG_WAVES_2X4, capi.FLAG_DMA_IN_L0,
+                                     capi.FLAG_WAVES_2X4 | capi.FLAG_DMA_IN_L0,
+                                     capi.FLAG_WAVES_2X4 | capi.FLAG_LOCKSTEP])
+def test_tile256_schedule_variants_agree(port, variant):
+    """Every wave-grid / schedule variant of the 256-tile kernel (default: 1 x 8 waves, ping-pong, DMA in
+    the MFMA section) accumulates each output in the same k order, so all give the same bits."""
     rng = np.random.default_rng(31)
     M, N, K = 512, 512, 704
     q = rng.integers(-8, 8, (N, K)).astype(np.int8)
     bp = pack_on_device(q, K, N)
     a = f16_bits(rng.uniform(-1, 1, (M, K)))
     s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
-    pp = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
-    ls = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_256 | capi.FLAG_LOCKSTEP, expect_kernel=MFMA256)
-    np.testing.assert_array_equal(pp, ls)     # same per-wave accumulation order
+    base = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
+    other = run_fpaintb(a, bp, s, M, N, K, flags=capi.FLAG_TILE_256 | variant, expect_kernel=MFMA256)
+    np.testing.assert_array_equal(base, other)
     exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
-    check_err(bits_to_f32(pp, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+    check_err(bits_to_f32(base, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
 
 
 def test_tile256_splitk_and_slices(port):
