@@ -34,7 +34,8 @@ struct Mfma256
     static constexpr int A_TILE      = BM * A_ROW_BYTES;                    // 32 KiB
     static constexpr int B_TILE      = BN * B_ROW_BYTES;                    // 8 or 16 KiB
     static constexpr int STAGE       = A_TILE + B_TILE;
-    static constexpr int LDS_BYTES   = NBUF * STAGE;                        // 120 or 144 KiB
+    static constexpr int RING_BYTES  = NBUF * STAGE;                        // 120 or 144 KiB
+    static constexpr int LDS_BYTES   = RING_BYTES > kCTileBytes ? RING_BYTES : kCTileBytes; // the C tile image reuses the ring
     static constexpr int A_DMA       = A_TILE / 1024 / 8;                   // LDS-DMA instructions per wave per tile: 4
     static constexpr int B_DMA       = B_TILE / 1024 / 8;                   // 1 or 2
     static constexpr int DMA_PER_TILE = A_DMA + B_DMA;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
     int tm, tn;
     {
         const int nwg = p.tiles_m * p.tiles_n;
-        tile_coords(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, tm, tn);
+        tile_coords(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     }
     const int m0 = tm * T::BM, n0 = tn * T::BN;
 
@@ -349,7 +350,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
-    tile_epilogue<NT, MT>(p, acc, m0 + row_w, n0 + col_w, fr, fq);
+    // (every wave is past the last barrier of the loop: no LDS read or DMA of the ring is outstanding)
+    tile256_epilogue<NT, MT>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);
 }
 
 } // namespace wq

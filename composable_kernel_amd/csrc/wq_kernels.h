@@ -31,6 +31,8 @@ struct GemmParams
     int k_per_z;   // K extent handled by one blockIdx.z (split-K inside the GPU)
     int partial;   // 1: store raw fp32 accumulators to slab blockIdx.z of c (ld = ldc)
     int tiles_m, tiles_n;
+    int group_m;      // tile rows walked together by neighbouring workgroups (L2 / fabric locality)
+    int direct_store; // 256-tile kernel: store accumulator fragments directly (tuning A/B)
     EpilogueArgs epi;
 };
 
@@ -45,9 +47,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // Within the remapped order walk tiles in groups of 8 tile-rows so that concurrently resident
 // blocks share activation rows and weight columns in L2.
-__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn)
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int GROUP, int& tm, int& tn)
 {
-    constexpr int GROUP = 8;
     const int per_group = GROUP * tiles_n;
     const int g         = t / per_group;
     const int first_m   = g * GROUP;
@@ -107,6 +108,78 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
     }
 }
 
+// Epilogue of the 256 x 256 tile kernels for 16-bit outputs: every wave applies the epilogue to its
+// accumulators, converts and writes the 16-bit values into an LDS image of the whole C tile
+// (256 rows x 512 B, row pitch 528 B), then the workgroup streams the tile out row by row with
+// 16-byte stores: each wave-instruction writes two complete 512-byte rows of C, instead of the
+// 16 x 32-byte pieces a direct store of an MFMA accumulator fragment makes.
+constexpr int kCTilePitch = 528;
+constexpr int kCTileBytes = 256 * kCTilePitch;
+
+template <int KIND, bool BF16, int NT, int MT>
+__device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, const f4_t (&acc)[NT][MT], uint8_t* lds,
+                                                       int m0, int n0, int row_w, int col_w, int fr, int fq,
+                                                       int wave, int lane)
+{
+#pragma unroll
+    for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < MT; ++mt)
+        {
+            const int r = row_w + mt * 16 + fr, c = col_w + nt * 16 + fq * 4;
+            uint16_t o[4];
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+            {
+                const float y = apply_epilogue_k<KIND>(p.epi, acc[nt][mt][j], m0 + r, n0 + c + j);
+                o[j]          = BF16 ? f32_to_bf16_trunc(y) : __builtin_bit_cast(uint16_t, (_Float16)y);
+            }
+            u2_t pk;
+            pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+            pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+            *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
+        }
+    __syncthreads();
+    uint16_t* cg = (uint16_t*)p.c + (size_t)m0 * p.ldc + n0;
+#pragma unroll 4
+    for(int i = 0; i < 16; ++i)
+    {
+        const int r   = wave * 32 + 2 * i + (lane >> 5);
+        const int c16 = lane & 31;
+        const u4_t v  = *(const u4_t*)(lds + r * kCTilePitch + c16 * 16);
+        *(u4_t*)(cg + (size_t)r * p.ldc + c16 * 8) = v;
+    }
+}
+
+template <int NT, int MT>
+__device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t (&acc)[NT][MT], uint8_t* lds, int m0,
+                                                 int n0, int row_w, int col_w, int fr, int fq, int wave, int lane)
+{
+    if(p.partial || p.direct_store)
+    {
+        tile_epilogue<NT, MT>(p, acc, m0 + row_w, n0 + col_w, fr, fq);
+        return;
+    }
+    const bool bf = p.epi.c_dtype == 1;
+#define WQ_EPI_CASE(K)                                                                                              \
+    case K:                                                                                                         \
+        bf ? tile256_epilogue_lds_k<K, true>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane)                 \
+           : tile256_epilogue_lds_k<K, false>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);               \
+        break;
+    switch(p.epi.kind)
+    {
+        WQ_EPI_CASE(1)
+        WQ_EPI_CASE(2)
+        WQ_EPI_CASE(3)
+        WQ_EPI_CASE(4)
+    default:
+        bf ? tile256_epilogue_lds_k<0, true>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane)
+           : tile256_epilogue_lds_k<0, false>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);
+        break;
+    }
+#undef WQ_EPI_CASE
+}
+
 // ---------------------------------------------------------------------------------------------
 // 128 x 128 x 64 MFMA kernel
 // ---------------------------------------------------------------------------------------------
@@ -144,7 +217,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     int tm, tn;
     {
         const int nwg = p.tiles_m * p.tiles_n;
-        tile_coords(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, tm, tn);
+        tile_coords(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     }
     const int m0 = tm * T::BM, n0 = tn * T::BN;
     const int wm = wave & 1, wn = wave >> 1; // this wave's 64 x 64 quadrant of the block tile

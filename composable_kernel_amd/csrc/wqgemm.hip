@@ -65,7 +65,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DMA_IN_L0))
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DMA_IN_L0 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8))
         return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
@@ -162,7 +162,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
                        ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
     plan.route = tiled ? ROUTE_MFMA128 : ROUTE_GENERIC;
-    if(tiled && p->M % 256 == 0 && p->N % 256 == 0 && !(p->flags & WQ_FLAG_TILE_128))
+    if(tiled && p->M % 256 == 0 && p->N % 256 == 0 && p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
         const long wgs = (long)(p->M / 256) * (p->N / 256) * plan.k_batch;
@@ -249,6 +249,23 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.tiles_m   = p->M / tile;
         gp.tiles_n   = p->N / tile;
         gp.epi       = epilogue_of(p);
+        gp.direct_store = (p->flags & WQ_FLAG_DIRECT_STORE) ? 1 : 0;
+        {
+            // Tiles are dealt to the 8 XCDs in contiguous runs of nwg/8 (xcd_remap); inside a run the
+            // walk covers group_m tile rows x (run / group_m) tile columns.  Pick the group that
+            // minimises the bytes one XCD pulls through its L2: g rows of A plus run/g columns of B.
+            const double a_bytes = 2.0 * tile, b_bytes = (p->b_dtype == WQ_I4_PACKED ? 0.5 : 1.0) * tile;
+            const int run        = (gp.tiles_m * gp.tiles_n + 7) / 8;
+            int best = 1;
+            double best_cost = 1e30;
+            for(int g = 1; g <= 16 && g <= gp.tiles_m; g *= 2)
+            {
+                const double cost = g * a_bytes + ((run + g - 1) / g) * b_bytes;
+                if(cost <= best_cost)
+                    best_cost = cost, best = g;
+            }
+            gp.group_m = (p->flags & WQ_FLAG_GROUP8) ? 8 : best;
+        }
         const dim3 grid(gp.tiles_m * gp.tiles_n, 1, plan.k_batch);
         if(plan.route == ROUTE_MFMA256)
         {
