@@ -88,9 +88,42 @@ __device__ __forceinline__ u4_t dequant8_i4_f16(const ScaleReg<A_F16>& sc, const
     return r;
 }
 
-// SCHED: 0 lockstep (one barrier per K tile), 1 ping-pong with the DMA issued in the L0 section,
-//        2 ping-pong with the DMA issued between the MFMAs of the M1 section.
-template <int AK, int BKIND, int WM, int SCHED>
+// SCHED: 0 lockstep (one barrier per K tile),
+//        2 ping-pong, dequantisation in the L sections, DMA of tile t+2 issued between the MFMAs of M1(t),
+//        5 ping-pong where the L sections only fetch activation fragments (plus the DMA issue) and each
+//          MFMA section also dequantises, between its MFMAs, the weight fragments of its NEXT section.
+// The fp16 x int4 dequantisation cut into three short stages (bit tricks / exact integer / scale) so
+// that an MFMA section can slot a few VALU instructions between groups of MFMAs.  Applied in place.
+template <int STAGE>
+__device__ __forceinline__ void dequant8_i4_f16_stage(u4_t& v, const ScaleReg<A_F16>& sc, const I4Consts& c, uint32_t w)
+{
+    if constexpr(STAGE == 0)
+    {
+        const uint32_t w8 = w >> 8;
+        v[0]              = and_or(w, c.mask_lo, c.magic);
+        v[1]              = and_or(w, c.mask_hi, c.magic);
+        v[2]              = and_or(w8, c.mask_lo, c.magic);
+        v[3]              = and_or(w8, c.mask_hi, c.magic);
+    }
+    else if constexpr(STAGE == 1)
+    {
+        v[0] = as_u32(as_h2(v[0]) - c.k1032);
+        v[1] = as_u32(__builtin_elementwise_fma(as_h2(v[1]), c.k16th, c.km72));
+        v[2] = as_u32(as_h2(v[2]) - c.k1032);
+        v[3] = as_u32(__builtin_elementwise_fma(as_h2(v[3]), c.k16th, c.km72));
+    }
+    else
+    {
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+            v[i] = as_u32(as_h2(v[i]) * sc.s2);
+    }
+}
+
+// STAMP: diagnostic build only -- every wave of workgroup 0 accumulates, per section kind, the shader
+// cycles spent working and the cycles spent waiting at the section's barrier, and writes the sums to
+// p.dbg (no output value depends on them; the product never launches this instantiation).
+template <int AK, int BKIND, int WM, int SCHED, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
 {
     using T = Mfma256<BKIND>;
@@ -253,7 +286,258 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
 
-        if constexpr(SCHED == 0)
+        if constexpr(SCHED == 5)
+        {
+            // Sections per K tile t and wave ("early" = first wave of a SIMD, "late" = second, one barrier behind):
+            //   L0: DMA pieces [0, D0) of tile t+2; activation fragments of (t, k-step 0)                       b
+            //   M0: raw weights of (t, 1); MFMAs of (t, 0) interleaved with their dequantisation;
+            //       late waves: wait for tile t+1's DMA                                                           b
+            //   L1: DMA pieces [D0, D) of tile t+2; activation fragments of (t, 1);
+            //       early waves: wait for tile t+1's DMA                                                          b
+            //   M1: raw weights of (t+1, 0); MFMAs of (t, 1) interleaved with their dequantisation               b
+            // RAW: tile t+1 is first read in M1(t) (raw weights).  Early waves enter it behind barrier 4t+3 of
+            //      their own count, late waves behind their 4t+4; every wave has waited for its own DMA of tile
+            //      t+1 in the section that ends at ITS barrier 4t+3 (early: L1(t), late: M0(t)).
+            // WAR: ring slot of tile t-1 is re-staged from L0(t) on; its last reads (L1(t-1), M0(t-1)) are
+            //      retired by the lgkmcnt(0) in front of barriers that precede every L0(t).
+            constexpr int D  = T::DMA_PER_TILE;
+            constexpr int D0 = (D + 1) / 2;
+            auto stage_part = [&](int buf, int kt, auto first, auto last) __attribute__((always_inline)) {
+                uint8_t* sa = lds + buf * T::STAGE;
+                uint8_t* sb = sa + T::A_TILE;
+#pragma unroll
+                for(int i = first; i < last; ++i)
+                {
+                    if(i < T::A_DMA)
+                        glds16(a_src[i] + (size_t)kt * T::A_ROW_BYTES, sa + (wave * T::A_DMA + i) * 1024);
+                    else
+                        glds16(b_src[i - T::A_DMA] + (size_t)kt * T::B_ROW_BYTES,
+                               sb + (wave * T::B_DMA + (i - T::A_DMA)) * 1024);
+                }
+            };
+            constexpr std::integral_constant<int, 0> kD_begin{};
+            constexpr std::integral_constant<int, D0> kD_mid{};
+            constexpr std::integral_constant<int, D> kD_end{};
+
+            uint32_t raw4[NT];
+            u2_t raw8[NT];
+            auto read_raw = [&](int buf, int s) __attribute__((always_inline)) {
+                const uint8_t* sb = lds + buf * T::STAGE + T::A_TILE;
+#pragma unroll
+                for(int nt = 0; nt < NT; ++nt)
+                {
+                    const int col = col_w + nt * 16 + fr;
+                    if constexpr(BKIND == B_I4P)
+                        raw4[nt] = *(const uint32_t*)(sb + col * 32 + ((s ^ ((col >> 2) & 1)) << 4) + fq * 4);
+                    else
+                        raw8[nt] = *(const u2_t*)(sb + col * 64 + (((2 * s + (fq >> 1)) ^ ((col >> 2) & 3)) << 4) +
+                                                  (fq & 1) * 8);
+                }
+            };
+            auto dequant_raw = [&](u4_t(&out)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+                for(int nt = 0; nt < NT; ++nt)
+                {
+                    if constexpr(BKIND == B_I4P)
+                    {
+                        if constexpr(AK == A_F16)
+                            out[nt] = dequant8_i4_f16(sc[nt], i4c, raw4[nt]);
+                        else
+                            out[nt] = dequant8(sc[nt], raw4[nt], std::integral_constant<int, B_I4P>{});
+                    }
+                    else
+                    {
+                        if constexpr(AK == A_F16)
+                            out[nt] = dequant8_bytes_f16<BKIND>(sc[nt], raw8[nt]);
+                        else
+                            out[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], raw8[nt]);
+                    }
+                }
+            };
+            auto load_a = [&](int buf, int s) __attribute__((always_inline)) {
+                const uint8_t* sa = lds + buf * T::STAGE;
+#pragma unroll
+                for(int mt = 0; mt < MT; ++mt)
+                    af[mt] = *(const u4_t*)(sa + a_off[s] + mt * 16 * 128);
+            };
+            auto mfma_with = [&](const u4_t(&w)[NT], auto mt_begin, auto mt_end) __attribute__((always_inline)) {
+#pragma unroll
+                for(int mt = mt_begin; mt < mt_end; ++mt)
+#pragma unroll
+                    for(int nt = 0; nt < NT; ++nt)
+                    {
+                        if constexpr(AK == A_F16)
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                __builtin_bit_cast(h8_t, w[nt]), __builtin_bit_cast(h8_t, af[mt]), acc[nt][mt], 0, 0, 0);
+                        else
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf8_t, w[nt]), __builtin_bit_cast(bf8_t, af[mt]), acc[nt][mt], 0, 0, 0);
+                    }
+            };
+            unsigned long long t_work[4] = {0, 0, 0, 0}, t_wait[4] = {0, 0, 0, 0}, t_a = 0;
+            auto sync = [&](auto sec) __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned long long t_b = 0;
+                if constexpr(STAMP)
+                {
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b)::"memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_barrier();
+                if constexpr(STAMP)
+                {
+                    unsigned long long t_c;
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c)::"memory");
+                    t_work[sec] += t_b - t_a;
+                    t_wait[sec] += t_c - t_b;
+                    t_a = t_c;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            constexpr std::integral_constant<int, 0> kL0{};
+            constexpr std::integral_constant<int, 1> kM0{};
+            constexpr std::integral_constant<int, 2> kL1{};
+            constexpr std::integral_constant<int, 3> kM1{};
+
+            // One MFMA section.  The first quarter of the MFMAs goes out at once; then the raw weights of the
+            // next section are fetched from LDS, and the remaining MFMAs are issued in six groups with one
+            // piece of that section's dequantisation behind each group (piece j = stage j / NT of fragment
+            // j % NT for fp16 x int4; whole fragments for the other formats).
+            constexpr int kSteps      = 6;
+            constexpr int kMtPerStep  = (MT - MT / 4) / kSteps; // 2 (MT 16) or 1 (MT 8)
+            constexpr int kPiecesStep = NT * 3 / kSteps;        // 1 (NT 2) or 2 (NT 4)
+            static_assert(kMtPerStep * kSteps == MT - MT / 4 && kPiecesStep * kSteps == NT * 3);
+            auto dequant_piece = [&](u4_t(&out)[NT], auto piece) __attribute__((always_inline)) {
+                constexpr int j = decltype(piece)::value;
+                constexpr int stage = j / NT, nt = j % NT;
+                if constexpr(BKIND == B_I4P && AK == A_F16)
+                    dequant8_i4_f16_stage<stage>(out[nt], sc[nt], i4c, raw4[nt]);
+                else if constexpr(stage == 0)
+                {
+                    if constexpr(BKIND == B_I4P)
+                        out[nt] = dequant8(sc[nt], raw4[nt], std::integral_constant<int, B_I4P>{});
+                    else if constexpr(AK == A_F16)
+                        out[nt] = dequant8_bytes_f16<BKIND>(sc[nt], raw8[nt]);
+                    else
+                        out[nt] = dequant8_bytes_bf16<BKIND>(sc[nt], raw8[nt]);
+                }
+                // pin the piece here: without an opaque use the optimiser sinks this arithmetic to the MFMAs
+                // that consume it, i.e. into the head of the next MFMA section
+                asm volatile("" : "+v"(out[nt][0]), "+v"(out[nt][1]), "+v"(out[nt][2]), "+v"(out[nt][3]));
+            };
+            auto mfma_step = [&](const u4_t(&w)[NT], u4_t(&w_next)[NT], auto dq_t, auto step) __attribute__((always_inline)) {
+                constexpr int st  = decltype(step)::value;
+                constexpr bool dq = decltype(dq_t)::value;
+                mfma_with(w, std::integral_constant<int, MT / 4 + st * kMtPerStep>{},
+                          std::integral_constant<int, MT / 4 + (st + 1) * kMtPerStep>{});
+                if constexpr(dq)
+                {
+                    dequant_piece(w_next, std::integral_constant<int, st * kPiecesStep>{});
+                    if constexpr(kPiecesStep == 2)
+                        dequant_piece(w_next, std::integral_constant<int, st * kPiecesStep + 1>{});
+                    // spread the VALU instructions of the piece(s) over the MFMA gaps of this group
+#pragma unroll
+                    for(int i = 0; i + 1 < kMtPerStep * NT; ++i)
+                    {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mfma_section = [&](const u4_t(&w)[NT], u4_t(&w_next)[NT], auto dq, int raw_buf, int raw_s)
+                __attribute__((always_inline)) {
+                mfma_with(w, kMt0, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr(decltype(dq)::value)
+                    read_raw(raw_buf, raw_s); // behind the first MFMA: its operand wait must not cover this read
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_with(w, std::integral_constant<int, 1>{}, std::integral_constant<int, MT / 4>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(w, w_next, dq, std::integral_constant<int, 0>{});
+                mfma_step(w, w_next, dq, std::integral_constant<int, 1>{});
+                mfma_step(w, w_next, dq, std::integral_constant<int, 2>{});
+                mfma_step(w, w_next, dq, std::integral_constant<int, 3>{});
+                mfma_step(w, w_next, dq, std::integral_constant<int, 4>{});
+                mfma_step(w, w_next, dq, std::integral_constant<int, 5>{});
+            };
+
+            u4_t wf2[NT]; // weight fragments of the section after the current one
+            read_raw(0, 0);
+            dequant_raw(wf);
+            __builtin_amdgcn_sched_barrier(0);
+            if(late)
+                __builtin_amdgcn_s_barrier();
+            if constexpr(STAMP)
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a)::"memory");
+            int cur = 0;
+            // one K tile; HAS_NEXT (compile time) = a tile t+1 exists, so M1 prepares its first weight fragments
+            auto tile_body = [&](int t, auto has_next) __attribute__((always_inline)) {
+                constexpr bool HAS_NEXT = decltype(has_next)::value;
+                int nxt = cur + 1, nxt2 = cur + 2;
+                nxt     = nxt >= T::NBUF ? nxt - T::NBUF : nxt;
+                nxt2    = nxt2 >= T::NBUF ? nxt2 - T::NBUF : nxt2;
+                const bool more2 = t + 2 < ntiles;
+                // L0
+                if(more2)
+                    stage_part(nxt2, t + 2, kD_begin, kD_mid);
+                load_a(cur, 0);
+                sync(kL0);
+                // M0
+                __builtin_amdgcn_s_setprio(1);
+                mfma_section(wf, wf2, std::true_type{}, cur, 1);
+                __builtin_amdgcn_s_setprio(0);
+                if(late)
+                {
+                    if(more2)
+                        wait_vmcnt<D0>();
+                    else
+                        wait_vmcnt<0>();
+                }
+                sync(kM0);
+                // L1
+                if(more2)
+                    stage_part(nxt2, t + 2, kD_mid, kD_end);
+                load_a(cur, 1);
+                if(!late)
+                {
+                    if(more2)
+                        wait_vmcnt<D>();
+                    else
+                        wait_vmcnt<0>();
+                }
+                sync(kL1);
+                // M1
+                __builtin_amdgcn_s_setprio(1);
+                mfma_section(wf2, wf, std::integral_constant<bool, HAS_NEXT>{}, nxt, 0);
+                __builtin_amdgcn_s_setprio(0);
+                sync(kM1);
+                cur = nxt;
+            };
+            for(int t = 0; t + 1 < ntiles; ++t)
+                tile_body(t, std::true_type{});
+            tile_body(ntiles - 1, std::false_type{});
+            if(!late)
+                __builtin_amdgcn_s_barrier();
+            if constexpr(STAMP)
+            {
+                if(blockIdx.x == 0 && lane == 0 && p.dbg)
+                {
+                    unsigned long long* d = (unsigned long long*)p.dbg + wave * 8;
+#pragma unroll
+                    for(int i = 0; i < 4; ++i)
+                    {
+                        d[i]     = t_work[i];
+                        d[4 + i] = t_wait[i];
+                    }
+                }
+            }
+        }
+        else if constexpr(SCHED == 0)
         {
             int cur = 0; // buffer of tile t
             for(int t = 0; t < ntiles; ++t)
@@ -291,45 +575,55 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
             //   WAR: the buffer of tile t-1 is re-staged no earlier than L0(t) of the early group; the late
             //        group's last reads of it (its L1(t-1)) are retired by the lgkmcnt(0) in front of the
             //        barrier that the early group must pass before it starts L0(t).
-            auto section_end = [&]() __attribute__((always_inline)) {
+            unsigned long long t_work[4] = {0, 0, 0, 0}, t_wait[4] = {0, 0, 0, 0}, t_a = 0;
+            auto section_end = [&](auto sec) __attribute__((always_inline)) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned long long t_b = 0;
+                if constexpr(STAMP)
+                {
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b)::"memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 __builtin_amdgcn_s_barrier();
+                if constexpr(STAMP)
+                {
+                    unsigned long long t_c;
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c)::"memory");
+                    t_work[sec] += t_b - t_a;
+                    t_wait[sec] += t_c - t_b;
+                    t_a = t_c;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
+            constexpr std::integral_constant<int, 0> kL0{};
+            constexpr std::integral_constant<int, 1> kM0{};
+            constexpr std::integral_constant<int, 2> kL1{};
+            constexpr std::integral_constant<int, 3> kM1{};
             if(late)
                 __builtin_amdgcn_s_barrier();
+            if constexpr(STAMP)
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a)::"memory");
             int cur = 0;
             for(int t = 0; t < ntiles; ++t)
             {
                 int nxt2 = cur + 2;
                 nxt2     = nxt2 >= T::NBUF ? nxt2 - T::NBUF : nxt2;
                 // L0
-                if constexpr(SCHED == 1)
-                    if(t + 2 < ntiles)
-                        stage(nxt2, t + 2);
                 load_frags(cur, 0);
-                section_end();
+                section_end(kL0);
                 // M0
                 __builtin_amdgcn_s_setprio(1);
                 mfma_frags(kMt0, kMtEnd);
                 __builtin_amdgcn_s_setprio(0);
-                section_end();
+                section_end(kM0);
                 // L1
                 load_frags(cur, 1);
-                if constexpr(SCHED == 1)
-                {
-                    if(t + 2 < ntiles)
-                        wait_vmcnt<T::DMA_PER_TILE>();
-                    else
-                        wait_vmcnt<0>();
-                }
-                else
-                    wait_vmcnt<0>(); // only tile t+1's DMA (issued in M1(t-1) or the prologue) is outstanding
-                section_end();
+                wait_vmcnt<0>(); // only tile t+1's DMA (issued in M1(t-1) or the prologue) is outstanding
+                section_end(kL1);
                 // M1
                 __builtin_amdgcn_s_setprio(1);
-                if constexpr(SCHED == 2)
                 {
                     mfma_frags(kMt0, kMtHalf);
                     __builtin_amdgcn_sched_barrier(0);
@@ -338,14 +632,25 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_frags(kMtHalf, kMtEnd);
                 }
-                else
-                    mfma_frags(kMt0, kMtEnd);
                 __builtin_amdgcn_s_setprio(0);
-                section_end();
+                section_end(kM1);
                 cur = cur + 1 >= T::NBUF ? 0 : cur + 1;
             }
             if(!late)
                 __builtin_amdgcn_s_barrier();
+            if constexpr(STAMP)
+            {
+                if(blockIdx.x == 0 && lane == 0 && p.dbg)
+                {
+                    unsigned long long* d = (unsigned long long*)p.dbg + wave * 8;
+#pragma unroll
+                    for(int i = 0; i < 4; ++i)
+                    {
+                        d[i]     = t_work[i];
+                        d[4 + i] = t_wait[i];
+                    }
+                }
+            }
         }
     }
 

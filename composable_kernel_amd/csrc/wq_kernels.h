@@ -33,6 +33,7 @@ struct GemmParams
     int tiles_m, tiles_n;
     int group_m;      // tile rows walked together by neighbouring workgroups (L2 / fabric locality)
     int direct_store; // 256-tile kernel: store accumulator fragments directly (tuning A/B)
+    void* dbg;        // diagnostic builds only: per-wave cycle sums
     EpilogueArgs epi;
 };
 
@@ -351,6 +352,8 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     tile_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
 }
 
+#ifdef WQ_MAIN_TU // the non-template kernels below are emitted by wqgemm.hip only
+
 // ---------------------------------------------------------------------------------------------
 // Generic kernel: any M, N, K slice and strides; one thread per output element, fp32 accumulate
 // in ascending k (the reference's own evaluation order).
@@ -511,5 +514,7 @@ __global__ __launch_bounds__(256) void wq_pack_int4(const int8_t* __restrict__ q
         *(uint32_t*)(out + (size_t)n * ld_bytes + 4 * g) = w;
     }
 }
+
+#endif // WQ_MAIN_TU
 
 } // namespace wq

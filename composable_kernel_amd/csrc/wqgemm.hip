@@ -8,9 +8,17 @@
 #include <cstring>
 #include <type_traits>
 
+#define WQ_MAIN_TU
 #include "wqgemm.h"
 #include "wq_kernels.h"
-#include "wq_gemm_256.h"
+
+// The 256-tile kernels are compiled one translation unit per (activation, weight format) pair
+// (wq_inst_256.hip) so that the build runs in parallel.
+namespace wq {
+#define WQ_DECL_256(AK, BK) int launch_256_##AK##_##BK(const GemmParams& gp, dim3 grid, hipStream_t s, int variant);
+WQ_DECL_256(0, 0) WQ_DECL_256(0, 1) WQ_DECL_256(0, 2) WQ_DECL_256(1, 0) WQ_DECL_256(1, 1) WQ_DECL_256(1, 2)
+#undef WQ_DECL_256
+} // namespace wq
 
 namespace {
 
@@ -32,6 +40,8 @@ int fail(int code, const char* fmt, ...)
         if(e_ != hipSuccess)                                                                 \
             return fail(WQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
     } while(0)
+
+void* g_dbg = nullptr; // diagnostic stamp buffer (wqgemm_debug_section_cycles)
 
 enum Route
 {
@@ -65,7 +75,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DMA_IN_L0 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8))
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L))
         return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
@@ -193,37 +203,6 @@ void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
 }
 
-template <int AK, int BKIND, int WM, int SCHED>
-int launch_mfma256_v(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
-{
-    // more than 64 KiB of dynamic LDS must be opted into once per device
-    static bool opted_in[64] = {};
-    int dev                  = 0;
-    WQ_HIP(hipGetDevice(&dev));
-    constexpr int lds_bytes = wq::Mfma256<BKIND>::LDS_BYTES;
-    if(dev >= 0 && dev < 64 && !opted_in[dev])
-    {
-        WQ_HIP(hipFuncSetAttribute((const void*)wq::wq_gemm_mfma_256<AK, BKIND, WM, SCHED>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        opted_in[dev] = true;
-    }
-    hipLaunchKernelGGL((wq::wq_gemm_mfma_256<AK, BKIND, WM, SCHED>), grid, dim3(512), lds_bytes, s, gp);
-    return WQ_OK;
-}
-
-// variant = tuning bits of wqgemm_problem.flags: WQ_FLAG_LOCKSTEP, WQ_FLAG_WAVES_2X4, WQ_FLAG_DMA_IN_L0
-template <int AK, int BKIND>
-int launch_mfma256(const wq::GemmParams& gp, dim3 grid, hipStream_t s, int variant)
-{
-    const bool lockstep = variant & WQ_FLAG_LOCKSTEP, w2x4 = variant & WQ_FLAG_WAVES_2X4,
-               dma_l0 = variant & WQ_FLAG_DMA_IN_L0;
-    if(lockstep)
-        return w2x4 ? launch_mfma256_v<AK, BKIND, 2, 0>(gp, grid, s) : launch_mfma256_v<AK, BKIND, 1, 0>(gp, grid, s);
-    if(dma_l0)
-        return w2x4 ? launch_mfma256_v<AK, BKIND, 2, 1>(gp, grid, s) : launch_mfma256_v<AK, BKIND, 1, 1>(gp, grid, s);
-    return w2x4 ? launch_mfma256_v<AK, BKIND, 2, 2>(gp, grid, s) : launch_mfma256_v<AK, BKIND, 1, 2>(gp, grid, s);
-}
-
 int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipStream_t s)
 {
     void* out  = plan.partial && !plan.to_c ? workspace : p->c;
@@ -250,6 +229,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.tiles_n   = p->N / tile;
         gp.epi       = epilogue_of(p);
         gp.direct_store = (p->flags & WQ_FLAG_DIRECT_STORE) ? 1 : 0;
+        gp.dbg          = g_dbg;
         {
             // Tiles are dealt to the 8 XCDs in contiguous runs of nwg/8 (xcd_remap); inside a run the
             // walk covers group_m tile rows x (run / group_m) tile columns.  Pick the group that
@@ -272,13 +252,15 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
             const int ls = p->flags; // tuning A/B switches
             int rc;
             if(plan.ak == wq::A_F16)
-                rc = plan.bk == wq::B_I4P   ? launch_mfma256<wq::A_F16, wq::B_I4P>(gp, grid, s, ls)
-                     : plan.bk == wq::B_U8O ? launch_mfma256<wq::A_F16, wq::B_U8O>(gp, grid, s, ls)
-                                            : launch_mfma256<wq::A_F16, wq::B_I8>(gp, grid, s, ls);
+                rc = plan.bk == wq::B_I4P   ? wq::launch_256_0_0(gp, grid, s, ls)
+                     : plan.bk == wq::B_U8O ? wq::launch_256_0_1(gp, grid, s, ls)
+                                            : wq::launch_256_0_2(gp, grid, s, ls);
             else
-                rc = plan.bk == wq::B_I4P   ? launch_mfma256<wq::A_BF16, wq::B_I4P>(gp, grid, s, ls)
-                     : plan.bk == wq::B_U8O ? launch_mfma256<wq::A_BF16, wq::B_U8O>(gp, grid, s, ls)
-                                            : launch_mfma256<wq::A_BF16, wq::B_I8>(gp, grid, s, ls);
+                rc = plan.bk == wq::B_I4P   ? wq::launch_256_1_0(gp, grid, s, ls)
+                     : plan.bk == wq::B_U8O ? wq::launch_256_1_1(gp, grid, s, ls)
+                                            : wq::launch_256_1_2(gp, grid, s, ls);
+            if(rc == WQ_ERR_HIP)
+                return fail(WQ_ERR_HIP, "256-tile kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
             if(rc != WQ_OK)
                 return rc;
         }
@@ -530,6 +512,16 @@ int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, ui
             memcpy(out + (size_t)n * ld_bytes + 4 * g, &w, 4);
         }
     return WQ_OK;
+}
+
+// Diagnostic (not part of the public header): run p once with the stamped build of the default
+// 256-tile fp16 x int4 kernel; dev_buf receives 8 waves x {work[L0,M0,L1,M1], wait[L0,M0,L1,M1]} cycles.
+int wqgemm_debug_section_cycles(const wqgemm_problem* p, void* dev_buf, void* stream)
+{
+    g_dbg        = dev_buf;
+    const int rc = wqgemm_launch(p, nullptr, stream);
+    g_dbg        = nullptr;
+    return rc;
 }
 
 int wqgemm_reduce_finalize(const wqgemm_problem* p, const float* partials, int32_t k_batch,

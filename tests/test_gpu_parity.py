@@ -335,9 +335,8 @@ def test_tile256_kernel_other_formats(port, a_dtype, b_dtype):
     np.testing.assert_array_equal(got, exp)
 
 
-@pytest.mark.parametrize("variant", [capi.FLAG_LOCKSTEP, capi.FLAG_WAVES_2X4, capi.FLAG_DMA_IN_L0,
-                                     capi.FLAG_WAVES_2X4 | capi.FLAG_DMA_IN_L0,
-                                     capi.FLAG_WAVES_2X4 | capi.FLAG_LOCKSTEP, capi.FLAG_DIRECT_STORE,
+@pytest.mark.parametrize("variant", [capi.FLAG_LOCKSTEP, capi.FLAG_WAVES_2X4, capi.FLAG_DEQUANT_IN_L,
+                                     capi.FLAG_WAVES_2X4 | capi.FLAG_DEQUANT_IN_L, capi.FLAG_DIRECT_STORE,
                                      capi.FLAG_GROUP8])
 def test_tile256_schedule_variants_agree(port, variant):
     """Every wave-grid / schedule variant of the 256-tile kernel (default: 1 x 8 waves, ping-pong, DMA in
