@@ -37,7 +37,7 @@ def test_is_supported_and_routes():
     assert capi.kernel_name(_problem(M=512, N=512)) == "wq_gemm_mfma_128"   # too few 256-tiles to fill the chip
     assert capi.kernel_name(_problem(M=512, N=512, flags=capi.FLAG_TILE_256)) == "wq_gemm_mfma_256"
     assert not capi.is_supported(_problem(M=384, N=512, flags=capi.FLAG_TILE_256))
-    assert not capi.is_supported(_problem(flags=64))
+    assert not capi.is_supported(_problem(flags=1 << 20))   # unknown flag bits are rejected
     # ragged shapes fall back to the generic HIP kernel (still supported)
     p = _problem(M=33, N=17, K=72, lda=80, ldb=88, ldc=24)
     assert capi.is_supported(p) and capi.kernel_name(p) == "wq_gemm_generic"
