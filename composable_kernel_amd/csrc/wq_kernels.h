@@ -355,6 +355,115 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
 #ifdef WQ_MAIN_TU // the non-template kernels below are emitted by wqgemm.hip only
 
 // ---------------------------------------------------------------------------------------------
+// int8 x int8 -> int32 MFMA kernel with the Activation_Mul_Clamp requantisation epilogue
+// (example/14_gemm_quantization, client_example/09_quantization).  128 x 128 x 128 tile: with one
+// byte per element a 128-deep K tile has the same 128-byte rows as the fp16 kernel's 64-deep tile, so
+// staging, swizzle and fragment addressing are shared; both operands go HBM -> LDS by LDS-DMA and
+// straight into v_mfma_i32_16x16x64_i8 (16 consecutive k per lane and operand).  Weights are the
+// first operand: lane l owns C[m = l & 15][n = 4 (l >> 4) + j] and stores 4 int8 at once.
+// ---------------------------------------------------------------------------------------------
+struct I8GemmParams
+{
+    const void* a; // int8 row-major (M, lda)
+    const void* b; // int8, K contiguous per column n (ldb)
+    void* c;       // int8 row-major (M, ldc)
+    int M, N, K, lda, ldb, ldc;
+    int tiles_m, tiles_n, group_m;
+    float requant;
+};
+
+__global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
+{
+    constexpr int TILE = 128 * 128; // bytes of one operand tile
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * TILE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int ntiles = p.K / 128;
+
+    const uint8_t *a_src[4], *b_src[4];
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+    {
+        const int row   = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        a_src[i]        = (const uint8_t*)p.a + (size_t)(m0 + row) * p.lda + chunk * 16;
+        b_src[i]        = (const uint8_t*)p.b + (size_t)(n0 + row) * p.ldb + chunk * 16;
+    }
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
+        uint8_t* sa = lds + buf * 2 * TILE;
+        uint8_t* sb = sa + TILE;
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+        {
+            glds16(a_src[i] + (size_t)kt * 128, sa + (wave * 4 + i) * 1024);
+            glds16(b_src[i] + (size_t)kt * 128, sb + (wave * 4 + i) * 1024);
+        }
+    };
+
+    i4_t acc[4][4];
+#pragma unroll
+    for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < 4; ++mt)
+            acc[nt][mt] = i4_t{0, 0, 0, 0};
+
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const uint8_t* sa = lds + buf * 2 * TILE;
+        const uint8_t* sb = sa + TILE;
+#pragma unroll
+        for(int s = 0; s < 2; ++s) // two 64-deep MFMA steps per tile
+        {
+            i4_t wf[4], af[4];
+#pragma unroll
+            for(int t = 0; t < 4; ++t)
+            {
+                const int nrow = wn * 64 + t * 16 + fr, mrow = wm * 64 + t * 16 + fr;
+                wf[t] = *(const i4_t*)(sb + nrow * 128 + (((4 * s + fq) ^ (nrow & 7)) << 4));
+                af[t] = *(const i4_t*)(sa + mrow * 128 + (((4 * s + fq) ^ (mrow & 7)) << 4));
+            }
+#pragma unroll
+            for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for(int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    };
+
+    if(ntiles > 0)
+    {
+        stage(0, 0);
+        __syncthreads();
+        for(int t = 0; t < ntiles; ++t)
+        {
+            const int cur = t & 1;
+            if(t + 1 < ntiles)
+                stage(cur ^ 1, t + 1);
+            compute(cur);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < 4; ++mt)
+        {
+            const int m = m0 + wm * 64 + mt * 16 + fr, n = n0 + wn * 64 + nt * 16 + fq * 4;
+            uint32_t pk = 0;
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                pk |= (uint32_t)(uint8_t)act_mul_clamp(p.requant, acc[nt][mt][j]) << (8 * j);
+            *(uint32_t*)((int8_t*)p.c + (size_t)m * p.ldc + n) = pk;
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Generic kernel: any M, N, K slice and strides; one thread per output element, fp32 accumulate
 // in ascending k (the reference's own evaluation order).
 // ---------------------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ enum Route
     ROUTE_NONE = 0,
     ROUTE_MFMA128,
     ROUTE_MFMA256,
+    ROUTE_I8_MFMA128,
     ROUTE_GENERIC
 };
 
@@ -75,7 +76,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L))
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_GENERIC))
         return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
@@ -117,7 +118,11 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
             return fail(WQ_ERR_UNSUPPORTED, "int8 A needs int8 B, int8 C and Activation_Mul_Clamp");
         if(plan.partial)
             return fail(WQ_ERR_UNSUPPORTED, "split-K is not implemented for the int8 requant GEMM");
-        plan.route = ROUTE_GENERIC;
+        const bool tiled_i8 = p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->M % 128 == 0 &&
+                              p->N % 128 == 0 && p->K % 128 == 0 && p->lda % 16 == 0 && p->ldb % 16 == 0 &&
+                              p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 &&
+                              (uintptr_t)p->c % 4 == 0 && !(p->flags & WQ_FLAG_GENERIC);
+        plan.route = tiled_i8 ? ROUTE_I8_MFMA128 : ROUTE_GENERIC;
         return WQ_OK;
     }
 
@@ -171,8 +176,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                        p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
                        ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
-    plan.route = tiled ? ROUTE_MFMA128 : ROUTE_GENERIC;
-    if(tiled && p->M % 256 == 0 && p->N % 256 == 0 && p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
+    plan.route = tiled && !(p->flags & WQ_FLAG_GENERIC) ? ROUTE_MFMA128 : ROUTE_GENERIC;
+    if(plan.route == ROUTE_MFMA128 && p->M % 256 == 0 && p->N % 256 == 0 && p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
         const long wgs = (long)(p->M / 256) * (p->N / 256) * plan.k_batch;
@@ -282,6 +287,17 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
             else
                 launch_mfma128<wq::A_BF16, wq::B_I8>(gp, grid, s);
         }
+    }
+    else if(plan.route == ROUTE_I8_MFMA128)
+    {
+        wq::I8GemmParams gp;
+        gp.a = p->a, gp.b = p->b, gp.c = p->c;
+        gp.M = p->M, gp.N = p->N, gp.K = p->K;
+        gp.lda = p->lda, gp.ldb = p->ldb, gp.ldc = p->ldc;
+        gp.tiles_m = p->M / 128, gp.tiles_n = p->N / 128;
+        gp.group_m = gp.tiles_m >= 8 ? 8 : gp.tiles_m;
+        gp.requant = p->requant_scale;
+        hipLaunchKernelGGL(wq::wq_gemm_i8_mfma_128, dim3(gp.tiles_m * gp.tiles_n), dim3(256), 0, s, gp);
     }
     else
     {
@@ -446,7 +462,9 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
         snprintf(buf, n, "DeviceWqGemm_gfx950<unsupported>");
         return WQ_ERR_UNSUPPORTED;
     }
-    if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
+    if(plan.route == ROUTE_I8_MFMA128)
+        snprintf(buf, n, "DeviceGemmQuantization_Mfma_gfx950<256, 128, 128, 128, 16x16x64, I8, I8, I8, LdsDma>");
+    else if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
         snprintf(buf, n,
                  "DeviceFpAintBGemm_Mfma_gfx950<%s, 64, 16x16x32, %s, %s, %s, LdsDma, "
                  "DequantInRegister, KBatch%d>",
@@ -467,7 +485,8 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
     if(rc != WQ_OK)
         return rc;
     snprintf(buf, n, "%s",
-             plan.route == ROUTE_MFMA256   ? "wq_gemm_mfma_256"
+             plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
+             : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128"
                                            : "wq_gemm_generic");
     return WQ_OK;

@@ -65,6 +65,7 @@ typedef enum wq_epilogue
 #define WQ_FLAG_WAVES_2X4 8  /* 256-tile kernel with a 2 x 4 wave grid instead of 1 x 8 (tuning A/B) */
 #define WQ_FLAG_DIRECT_STORE 32 /* 256-tile kernel storing accumulator fragments directly, no LDS-staged epilogue (tuning A/B) */
 #define WQ_FLAG_DEQUANT_IN_L 512 /* 256-tile ping-pong kernel dequantising in the load sections, LDS-DMA in the second MFMA section (tuning A/B) */
+#define WQ_FLAG_GENERIC 1024     /* force the generic (one thread per output) kernel */
 #define WQ_FLAG_GROUP8 64       /* walk tiles in groups of 8 tile rows instead of the cost-minimising group (tuning A/B) */
 
 /* One GEMM problem: C[M,N] = epilogue( sum_k A[m,k] * dequant(B[k,n], scale[n]) ).

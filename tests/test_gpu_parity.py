@@ -168,19 +168,58 @@ def test_bf16_int8_mfma(port):
     np.testing.assert_array_equal(got, exp)
 
 
+def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None):
+    a_t, b_t = dev(a), dev(b)
+    ldc = ldc or N
+    e_t = torch.full((M, ldc), 77, dtype=torch.int8, device="cuda")
+    p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), None, e_t.data_ptr(), M, N, K, a_dtype=capi.I8,
+                             b_dtype=capi.I8, c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=requant,
+                             flags=flags, lda=lda, ldb=ldb, ldc=ldc)
+    assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
+    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return e_t.cpu().numpy(), capi.kernel_name(p)
+
+
 def test_c1_int8_requant_gemm_exact(golden_gemm, port):
-    """example/14 problem (M=N=K=256, srand(1) inputs, requant 0.03) on the GPU: atol 0."""
+    """example/14 problem (M=N=K=256, srand(1) inputs, requant 0.03) on the GPU: atol 0, on both the
+    int8 MFMA kernel and the generic kernel."""
     M = N = K = 256
     a = port.generator2_i8(M, K, K, 1, -128, 127, seed=1)
     b = port.generator2_i8(K, N, 1, K, -128, 127, seed=-1)
-    a_t, b_t = dev(a), dev(b)
-    e_t = torch.zeros((M, N), dtype=torch.int8, device="cuda")
-    p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), None, e_t.data_ptr(), M, N, K, a_dtype=capi.I8,
-                             b_dtype=capi.I8, c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=0.03)
-    assert capi.is_supported(p)
-    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(e_t.cpu().numpy(), golden_gemm["c1_e"])
+    e, name = _run_i8(a, b, M, N, K, 0.03)
+    assert name == "wq_gemm_i8_mfma_128"
+    np.testing.assert_array_equal(e, golden_gemm["c1_e"])
+    e, name = _run_i8(a, b, M, N, K, 0.03, flags=capi.FLAG_GENERIC)
+    assert name == GENERIC
+    np.testing.assert_array_equal(e, golden_gemm["c1_e"])
+
+
+def test_int8_requant_golden_ragged_and_large(golden_gemm, port):
+    g = golden_gemm
+    # ragged strides / sizes (40 x 24 x 96): generic kernel, golden from the reference
+    e, name = _run_i8(g["i8_small_a"], g["i8_small_b"], 40, 24, 96, 0.25, lda=104, ldb=100, ldc=32)
+    assert name == GENERIC
+    exp = np.full(40 * 32, 77, np.int8)
+    exp[: g["i8_small_e"].size] = g["i8_small_e"]
+    np.testing.assert_array_equal(e[:, :24], exp.reshape(40, 32)[:, :24])
+    # example/14's own size (1024^3, |acc| <= 2^24 so the reference's float accumulate is exact): MFMA kernel
+    # against the checker on a row block and against the generic kernel everywhere
+    rng = np.random.default_rng(14)
+    M = N = K = 1024
+    a = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    e, name = _run_i8(a, b, M, N, K, 0.03)
+    assert name == "wq_gemm_i8_mfma_128"
+    eg, _ = _run_i8(a, b, M, N, K, 0.03, flags=capi.FLAG_GENERIC)
+    np.testing.assert_array_equal(e, eg)
+    ref = port.gemm_i8_requant(np.ascontiguousarray(a[:64]), b, 64, N, K, K, K, N, 0.03).reshape(64, N)
+    np.testing.assert_array_equal(e[:64], ref)
+    # small requant scale so that outputs are not saturated
+    e, _ = _run_i8(a, b, M, N, K, 1e-4)
+    ref = port.gemm_i8_requant(np.ascontiguousarray(a[:64]), b, 64, N, K, K, K, N, 1e-4).reshape(64, N)
+    np.testing.assert_array_equal(e[:64], ref)
+    assert np.abs(ref.astype(np.int32)).max() < 127 and np.unique(ref).size > 20
 
 
 def test_f8_int4_multiply_multiply_generic(golden_gemm):
