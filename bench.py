@@ -95,6 +95,21 @@ def cpu_baseline_leg(a, q, s, c_gpu, M, N, K, budget_s=12.0):
     }
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed counter summary (separate rocprofv3 --pmc passes for
+    FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as gfx950 requires; tools/pmc_summary.py), or None when the
+    summary is absent or belongs to another kernel.  Counters cannot be collected from inside this process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_mfma256_pmc.json")
+    try:
+        with open(path) as fh:
+            summary = json.load(fh)
+    except OSError:
+        return None
+    if not any(kernel in k for k in summary.get("kernel", [])):
+        return None
+    return summary.get("hbm_bytes_per_launch")
+
+
 def run_single(args):
     dev = torch.device("cuda", 0)
     M = N = K = 4096
@@ -143,7 +158,7 @@ def run_single(args):
         "hbm_frac_of_peak": nbytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
         "roofline": {"bound": "mfma", "achieved": kern_tflops, "peak": PEAK_FP16_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": kern_tflops / PEAK_FP16_MFMA_TFLOPS,
-                     "traffic": None, "kernel_ms": kern_ms,
+                     "traffic": pmc_traffic(capi.kernel_name(p)), "kernel_ms": kern_ms,
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes},
     }
     if not args.no_cpu:
