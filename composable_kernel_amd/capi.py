@@ -21,12 +21,12 @@ LIB_PATH = os.path.join(HERE, "csrc", "libwqgemm.so")
 # wq_status
 OK, ERR_UNSUPPORTED, ERR_INVALID, ERR_HIP, ERR_WORKSPACE = range(5)
 # wq_dtype
-F16, BF16, F8_FNUZ, F32, I8, U8_OFFSET, I4_PACKED, I32 = range(8)
+F16, BF16, F8_FNUZ, F32, I8, U8_OFFSET, I4_PACKED, I32, F8_E4M3FN = range(9)
 # wq_layout
 ROW_MAJOR, COL_MAJOR = 0, 1
 # wqgemm_problem.flags
 FLAG_TILE_128, FLAG_TILE_256, FLAG_LOCKSTEP, FLAG_WAVES_2X4 = 1, 2, 4, 8
-FLAG_DIRECT_STORE, FLAG_GROUP8, FLAG_DEQUANT_IN_L, FLAG_GENERIC = 32, 64, 512, 1024
+FLAG_DIRECT_STORE, FLAG_GROUP8, FLAG_DEQUANT_IN_L, FLAG_GENERIC, FLAG_F8_NO_SPECIALS = 32, 64, 512, 1024, 2048
 # wq_epilogue
 (EPI_PASSTHROUGH, EPI_FASTGELU, EPI_MULTIPLY_ADD_FASTGELU, EPI_MULTIPLY_MULTIPLY,
  EPI_MULTIPLY_MULTIPLY_FASTGELU, EPI_ACT_MUL_CLAMP) = range(6)

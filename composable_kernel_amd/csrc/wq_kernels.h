@@ -33,6 +33,7 @@ struct GemmParams
     int tiles_m, tiles_n;
     int group_m;      // tile rows walked together by neighbouring workgroups (L2 / fabric locality)
     int direct_store; // 256-tile kernel: store accumulator fragments directly (tuning A/B)
+    int a_scale;      // fp8 kernel: E8M0 block scale of the activation operand, replicated in all 4 bytes
     void* dbg;        // diagnostic builds only: per-wave cycle sums
     EpilogueArgs epi;
 };
@@ -493,6 +494,17 @@ __device__ __forceinline__ float f8_fnuz_to_f32(uint8_t x)
     return (x & 0x80) ? -v : v;
 }
 
+__device__ __forceinline__ float f8_e4m3fn_to_f32(uint8_t x)
+{
+    // OCP E4M3 ("e4m3fn"): bias 7, S.1111.111 = NaN, no infinities, subnormals m * 2^-9
+    if((x & 0x7F) == 0x7F)
+        return __builtin_nanf("");
+    const int e   = (x >> 3) & 15;
+    const int m   = x & 7;
+    const float v = e == 0 ? (float)m * 0.001953125f : __builtin_ldexpf((float)(8 + m), e - 10);
+    return (x & 0x80) ? -v : v;
+}
+
 __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
 {
     const int n = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -541,10 +553,11 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
             va = bf16_to_f32(((const uint16_t*)p.a)[m * p.a_sm + k * p.a_sk]);
             vb = dequant_scalar<A_BF16>(q, sbits);
         }
-        else /* WQ_F8_FNUZ: scales live in the epilogue */
+        else /* fp8: scales live in the epilogue */
         {
-            va = f8_fnuz_to_f32(((const uint8_t*)p.a)[m * p.a_sm + k * p.a_sk]);
-            vb = (float)q;
+            const uint8_t x = ((const uint8_t*)p.a)[m * p.a_sm + k * p.a_sk];
+            va              = p.a_dtype == 8 /*WQ_F8_E4M3FN*/ ? f8_e4m3fn_to_f32(x) : f8_fnuz_to_f32(x);
+            vb              = (float)q;
         }
         acc += va * vb;
     }

@@ -18,6 +18,7 @@ namespace wq {
 #define WQ_DECL_256(AK, BK) int launch_256_##AK##_##BK(const GemmParams& gp, dim3 grid, hipStream_t s, int variant);
 WQ_DECL_256(0, 0) WQ_DECL_256(0, 1) WQ_DECL_256(0, 2) WQ_DECL_256(1, 0) WQ_DECL_256(1, 1) WQ_DECL_256(1, 2)
 #undef WQ_DECL_256
+int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant); // wq_inst_256_f8.hip
 } // namespace wq
 
 namespace {
@@ -49,6 +50,7 @@ enum Route
     ROUTE_MFMA128,
     ROUTE_MFMA256,
     ROUTE_I8_MFMA128,
+    ROUTE_F8_MFMA256,
     ROUTE_GENERIC
 };
 
@@ -76,7 +78,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_GENERIC))
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_GENERIC | WQ_FLAG_F8_NO_SPECIALS))
         return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
@@ -127,7 +129,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     }
 
     // ---- fpAintB family ------------------------------------------------------------------------
-    if(p->a_dtype != WQ_F16 && p->a_dtype != WQ_BF16 && p->a_dtype != WQ_F8_FNUZ)
+    if(p->a_dtype != WQ_F16 && p->a_dtype != WQ_BF16 && p->a_dtype != WQ_F8_FNUZ && p->a_dtype != WQ_F8_E4M3FN)
         return fail(WQ_ERR_UNSUPPORTED, "unsupported A dtype %d", p->a_dtype);
     if(p->b_dtype != WQ_I4_PACKED && p->b_dtype != WQ_U8_OFFSET && p->b_dtype != WQ_I8)
         return fail(WQ_ERR_UNSUPPORTED, "unsupported B dtype %d", p->b_dtype);
@@ -177,6 +179,15 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
                        ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
     plan.route = tiled && !(p->flags & WQ_FLAG_GENERIC) ? ROUTE_MFMA128 : ROUTE_GENERIC;
+    // fp8 activations x packed int4 weights on the fp8 matrix core (scales arrive through the epilogue).
+    // FNUZ bytes qualify only when the caller excludes the three encodings E4M3FN cannot express.
+    const bool is_f8 = p->a_dtype == WQ_F8_FNUZ || p->a_dtype == WQ_F8_E4M3FN;
+    if(is_f8 && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
+       p->b_dtype == WQ_I4_PACKED && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->M % 256 == 0 && p->N % 256 == 0 &&
+       plan.k_begin % 128 == 0 && plan.k_per_z % 128 == 0 && (plan.k_end - plan.k_begin) % 128 == 0 &&
+       p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
+       (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
+        plan.route = ROUTE_F8_MFMA256;
     if(plan.route == ROUTE_MFMA128 && p->M % 256 == 0 && p->N % 256 == 0 && p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
@@ -212,9 +223,9 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
 {
     void* out  = plan.partial && !plan.to_c ? workspace : p->c;
     const int ld_out = plan.partial && !plan.to_c ? p->N : p->ldc;
-    if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
+    if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256 || plan.route == ROUTE_F8_MFMA256)
     {
-        const int tile = plan.route == ROUTE_MFMA256 ? 256 : 128;
+        const int tile = plan.route == ROUTE_MFMA128 ? 128 : 256;
         wq::GemmParams gp;
         gp.a         = p->a;
         gp.b         = p->b;
@@ -235,11 +246,12 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.epi       = epilogue_of(p);
         gp.direct_store = (p->flags & WQ_FLAG_DIRECT_STORE) ? 1 : 0;
         gp.dbg          = g_dbg;
+        gp.a_scale      = p->a_dtype == WQ_F8_FNUZ ? 0x7E7E7E7E : 0x7F7F7F7F;
         {
             // Tiles are dealt to the 8 XCDs in contiguous runs of nwg/8 (xcd_remap); inside a run the
             // walk covers group_m tile rows x (run / group_m) tile columns.  Pick the group that
             // minimises the bytes one XCD pulls through its L2: g rows of A plus run/g columns of B.
-            const double a_bytes = 2.0 * tile, b_bytes = (p->b_dtype == WQ_I4_PACKED ? 0.5 : 1.0) * tile;
+            const double a_bytes = (plan.route == ROUTE_F8_MFMA256 ? 1.0 : 2.0) * tile, b_bytes = (p->b_dtype == WQ_I4_PACKED ? 0.5 : 1.0) * tile;
             const int run        = (gp.tiles_m * gp.tiles_n + 7) / 8;
             int best = 1;
             double best_cost = 1e30;
@@ -252,7 +264,13 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
             gp.group_m = (p->flags & WQ_FLAG_GROUP8) ? 8 : best;
         }
         const dim3 grid(gp.tiles_m * gp.tiles_n, 1, plan.k_batch);
-        if(plan.route == ROUTE_MFMA256)
+        if(plan.route == ROUTE_F8_MFMA256)
+        {
+            const int rc = wq::launch_256_f8(gp, grid, s, p->flags);
+            if(rc == WQ_ERR_HIP)
+                return fail(WQ_ERR_HIP, "fp8 256-tile kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        else if(plan.route == ROUTE_MFMA256)
         {
             const int ls = p->flags; // tuning A/B switches
             int rc;
@@ -355,6 +373,7 @@ const char* dt_name(int dt)
     case WQ_F16: return "F16";
     case WQ_BF16: return "BF16";
     case WQ_F8_FNUZ: return "F8";
+    case WQ_F8_E4M3FN: return "F8_E4M3FN";
     case WQ_F32: return "F32";
     case WQ_I8: return "I8";
     case WQ_U8_OFFSET: return "U8";
@@ -464,6 +483,11 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
     }
     if(plan.route == ROUTE_I8_MFMA128)
         snprintf(buf, n, "DeviceGemmQuantization_Mfma_gfx950<256, 128, 128, 128, 16x16x64, I8, I8, I8, LdsDma>");
+    else if(plan.route == ROUTE_F8_MFMA256)
+        snprintf(buf, n,
+                 "DeviceGemmMultiplyMultiply_WeightQuant_Mfma_gfx950<512, 256, 256, 128, 16x16x128_f8f6f4, %s, %s, %s, "
+                 "LdsDma, ConvertInRegister, KBatch%d>",
+                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
     else if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
         snprintf(buf, n,
                  "DeviceFpAintBGemm_Mfma_gfx950<%s, 64, 16x16x32, %s, %s, %s, LdsDma, "
@@ -487,6 +511,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
     snprintf(buf, n, "%s",
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
+             : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"
              : plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128"
                                            : "wq_gemm_generic");
     return WQ_OK;

@@ -37,7 +37,8 @@ typedef enum wq_dtype
     WQ_I8        = 4, /* signed int8, one byte per element                                           */
     WQ_U8_OFFSET = 5, /* uint8 = int8 + 128 (example/64_fpAintB_gemm/common.hpp:51-83)               */
     WQ_I4_PACKED = 6, /* two offset-binary nibbles per byte, layout documented at wqgemm_pack_int4   */
-    WQ_I32       = 7
+    WQ_I32       = 7,
+    WQ_F8_E4M3FN = 8  /* OCP E4M3 ("e4m3fn") bytes, bias 7, 0x7F/0xFF = NaN: the fp8 the gfx950 matrix core decodes; no counterpart in the reference, whose f8_t is FNUZ only */
 } wq_dtype;
 
 typedef enum wq_layout
@@ -66,6 +67,7 @@ typedef enum wq_epilogue
 #define WQ_FLAG_DIRECT_STORE 32 /* 256-tile kernel storing accumulator fragments directly, no LDS-staged epilogue (tuning A/B) */
 #define WQ_FLAG_DEQUANT_IN_L 512 /* 256-tile ping-pong kernel dequantising in the load sections, LDS-DMA in the second MFMA section (tuning A/B) */
 #define WQ_FLAG_GENERIC 1024     /* force the generic (one thread per output) kernel */
+#define WQ_FLAG_F8_NO_SPECIALS 2048 /* WQ_F8_FNUZ activations hold none of the bytes 0x7F, 0xFF (+-240) and 0x80 (NaN): allows the fp8 matrix-core kernel, which reads FNUZ bytes as E4M3FN / 2 and cannot express those three */
 #define WQ_FLAG_GROUP8 64       /* walk tiles in groups of 8 tile rows instead of the cost-minimising group (tuning A/B) */
 
 /* One GEMM problem: C[M,N] = epilogue( sum_k A[m,k] * dequant(B[k,n], scale[n]) ).

@@ -51,7 +51,7 @@ def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b
         a_dtype=a_dtype, b_dtype=b_dtype, lda=lda, ldb=ldb, ldc=ldc, epilogue=epilogue,
         d0=d0_t.data_ptr() if d0_t is not None else None, d1=d1_t.data_ptr() if d1_t is not None else None,
         k_batch=k_batch, b_layout=b_layout, flags=flags,
-        c_dtype=(capi.F16 if a_dtype == capi.F8_FNUZ else None))
+        c_dtype=(capi.F16 if a_dtype in (capi.F8_FNUZ, capi.F8_E4M3FN) else None))
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     if expect_kernel is not None:
         assert capi.kernel_name(p) == expect_kernel, (capi.kernel_name(p), capi.type_string(p))

@@ -237,6 +237,103 @@ def test_f8_int4_multiply_multiply_generic(golden_gemm):
             check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
 
 
+F8_MFMA = "wq_gemm_f8_mfma_256"
+
+
+def _f8_bytes(rng, shape, exclude=(0x7F, 0xFF, 0x80)):
+    """Uniform random fp8 bytes without the given encodings."""
+    allowed = np.array([b for b in range(256) if b not in exclude], dtype=np.uint8)
+    return allowed[rng.integers(0, allowed.size, shape)]
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (256, 512, 384), (512, 256, 1024)])
+def test_f8_mfma_fnuz_vs_checker(port, M, N, K):
+    """fp8 FNUZ bytes x packed int4 on the fp8 matrix core (caller excludes 0x7F/0xFF/0x80), MultiplyMultiply
+    [+ FastGelu], against the CPU checker and the generic kernel."""
+    rng = np.random.default_rng(M + N + K)
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    d0 = rng.uniform(0.0, 1.0, N).astype(np.float32)
+    d1 = rng.uniform(0.0, 1.0, M).astype(np.float32)
+    # exact set: activations in {-2..2} (bytes of exactly representable integers), power-of-two scales
+    lut = {0: 0x00, 1: 0x40, 2: 0x48, -1: 0xC0, -2: 0xC8}
+    a_int = rng.integers(-2, 3, (M, K))
+    a = np.vectorize(lut.get)(a_int).astype(np.uint8)
+    d0e = (2.0 ** rng.integers(-3, 1, N)).astype(np.float32)
+    d1e = (2.0 ** rng.integers(-3, 1, M)).astype(np.float32)
+    got = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0e, d1=d1e,
+                      flags=capi.FLAG_F8_NO_SPECIALS, expect_kernel=F8_MFMA)
+    exp = port.gemm_f8_i8_mm(a, q, d0e, d1e, M, N, K, K, K, N, False).reshape(M, N)
+    np.testing.assert_array_equal(got, exp)
+    # realistic set: activations ~ U(-1, 1) rounded to fp8 FNUZ (the value range of the reference's own
+    # GeneratorTensor_3 inputs, example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8.cpp:170-190):
+    # check_err defaults for a half output
+    a = torch.from_numpy(rng.uniform(-1, 1, (M, K)).astype(np.float32)).to(torch.float8_e4m3fnuz).view(torch.uint8).numpy()
+    a[(a == 0x80)] = 0
+    for gelu, kind in ((False, capi.EPI_MULTIPLY_MULTIPLY), (True, capi.EPI_MULTIPLY_MULTIPLY_FASTGELU)):
+        got = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=kind, d0=d0, d1=d1,
+                          flags=capi.FLAG_F8_NO_SPECIALS, expect_kernel=F8_MFMA)
+        exp = port.gemm_f8_i8_mm(a, q, d0, d1, M, N, K, K, K, N, gelu).reshape(M, N)
+        check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+        gen = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=kind, d0=d0, d1=d1,
+                          expect_kernel=GENERIC)
+        if not gelu:
+            np.testing.assert_array_equal(gen, exp)
+    # adversarial set: uniformly random bytes (magnitudes log-uniform over 2^-10 .. 224).  The fp8 matrix core
+    # aligns the products of one lane's 32 k to the largest of them and drops what lies more than ~14 bits
+    # below it, so the stated bound gains a term relative to sum_k |a q|: 2^-12 * sum|a q| * d0 * d1.
+    a = _f8_bytes(rng, (M, K))
+    got = bits_to_f32(run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0,
+                                  d1=d1, flags=capi.FLAG_F8_NO_SPECIALS, expect_kernel=F8_MFMA), capi.F16)
+    exp = bits_to_f32(port.gemm_f8_i8_mm(a, q, d0, d1, M, N, K, K, K, N, False).reshape(M, N), capi.F16)
+    a_abs = np.abs(torch.from_numpy(a).view(torch.float8_e4m3fnuz).to(torch.float64).numpy())
+    terms = (a_abs @ np.abs(q.astype(np.float64)).T) * d0[None, :] * d1[:, None]
+    assert (np.abs(got.astype(np.float64) - exp) <= 1e-3 + 1e-3 * np.abs(exp) + 2.0 ** -12 * terms).all()
+    # without the caller's promise FNUZ data stays on the exact kernel
+    got = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0, d1=d1,
+                      expect_kernel=GENERIC)
+
+
+def test_f8_mfma_e4m3fn(port):
+    """E4M3FN (OCP) bytes: every encoding is native to the matrix core.  Finite bytes decode to twice the FNUZ
+    value of the same byte, so the FNUZ checker with d1 doubled is the exact expectation; NaN bytes (0x7F, 0xFF)
+    poison their row; the generic kernel and torch's float8_e4m3fn decode agree."""
+    rng = np.random.default_rng(65)
+    M, N, K = 256, 256, 512
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    d0 = rng.uniform(0.0, 1.0, N).astype(np.float32)
+    d1 = rng.uniform(0.0, 1.0, M).astype(np.float32)
+    a = torch.from_numpy(rng.uniform(-1, 1, (M, K)).astype(np.float32)).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    a[(a == 0x80)] = 0
+    got = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_E4M3FN, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0, d1=d1,
+                      expect_kernel=F8_MFMA)
+    exp = port.gemm_f8_i8_mm(a, q, d0, 2.0 * d1, M, N, K, K, K, N, False).reshape(M, N)
+    check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+    gen = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_E4M3FN, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0, d1=d1,
+                      flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
+    np.testing.assert_array_equal(gen, exp)
+    # independent decode: torch.float8_e4m3fn on the CPU, float64 accumulation
+    a_f = torch.from_numpy(a).view(torch.float8_e4m3fn).to(torch.float64)
+    ref = (a_f @ torch.from_numpy(q).to(torch.float64).T) * torch.from_numpy(d0).double()[None, :] \
+        * torch.from_numpy(d1).double()[:, None]
+    check_err(bits_to_f32(got, capi.F16), ref.numpy().astype(np.float32), 2e-3, 2e-3)
+    # -0 (0x80) is an ordinary zero, NaN bytes poison exactly their rows
+    a2 = a.copy()
+    a2[3, 5] = 0x80
+    a2[7, 100] = 0x7F
+    a2[200, 511] = 0xFF
+    got2 = bits_to_f32(run_fpaintb(a2, bp, None, M, N, K, a_dtype=capi.F8_E4M3FN, epilogue=capi.EPI_MULTIPLY_MULTIPLY,
+                                   d0=d0, d1=d1, expect_kernel=F8_MFMA), capi.F16)
+    gen2 = bits_to_f32(run_fpaintb(a2, bp, None, M, N, K, a_dtype=capi.F8_E4M3FN, epilogue=capi.EPI_MULTIPLY_MULTIPLY,
+                                   d0=d0, d1=d1, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC), capi.F16)
+    nan_rows = np.isnan(got2).all(axis=1)
+    assert nan_rows[7] and nan_rows[200] and nan_rows.sum() == 2
+    assert (np.isnan(gen2).all(axis=1) == nan_rows).all()
+    ok = ~nan_rows
+    check_err(got2[ok], gen2[ok], 1e-3, 1e-3)
+
+
 @pytest.mark.parametrize("k_batch", [2, 3, 5, 8])
 def test_splitk_in_gpu(port, k_batch):
     """k_batches of the reference's split-K tests (test/gemm_split_k/test_gemm_splitk_util.hpp:36-87)."""

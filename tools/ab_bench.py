@@ -25,15 +25,24 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--variants", default="0,4,1")
-    ap.add_argument("--a", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--a", default="f16", choices=["f16", "bf16", "f8", "f8fnuz"])
+    ap.add_argument("--ramp", type=int, default=1000, help="untimed launches before timing (clock settling)")
     ap.add_argument("--b", default="i4", choices=["i4", "i8", "u8"])
     args = ap.parse_args()
     M, N, K = args.M, args.N, args.K
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(1)
-    adt = torch.float16 if args.a == "f16" else torch.bfloat16
-    a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).to(adt)
+    is_f8 = args.a in ("f8", "f8fnuz")
+    adt = torch.float16 if args.a in ("f16", "f8", "f8fnuz") else torch.bfloat16
+    if is_f8:
+        # random fp8 bytes with exponent fields 1..14 (no NaN / maximum encodings in either E4M3 flavour)
+        a = (torch.randint(8, 120, (M, K), generator=g, device=dev, dtype=torch.int16) +
+             128 * torch.randint(0, 2, (M, K), generator=g, device=dev, dtype=torch.int16)).to(torch.uint8)
+        d0 = torch.rand((N,), generator=g, device=dev)
+        d1 = torch.rand((M,), generator=g, device=dev)
+    else:
+        a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).to(adt)
     s = (torch.rand((N,), generator=g, device=dev) * (2.0 ** -4 - 2.0 ** -8) + 2.0 ** -8).to(adt)
     if args.b == "i4":
         q = torch.randint(-8, 8, (N, K), generator=g, device=dev, dtype=torch.int8)
@@ -49,8 +58,14 @@ def main():
     variants = [int(v) for v in args.variants.split(",")]
     probs = {}
     for v in variants:
-        p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K,
-                                 a_dtype=capi.F16 if args.a == "f16" else capi.BF16, b_dtype=bdt, flags=v)
+        if is_f8:
+            p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), None, c.data_ptr(), M, N, K,
+                                     a_dtype=capi.F8_E4M3FN if args.a == "f8" else capi.F8_FNUZ, b_dtype=bdt,
+                                     c_dtype=capi.F16, epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU,
+                                     d0=d0.data_ptr(), d1=d1.data_ptr(), flags=v)
+        else:
+            p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K,
+                                     a_dtype=capi.F16 if args.a == "f16" else capi.BF16, b_dtype=bdt, flags=v)
         if not capi.is_supported(p):
             print(f"variant {v}: unsupported ({capi.lib.wqgemm_last_error().decode()})")
             continue
@@ -58,6 +73,8 @@ def main():
     times = {v: [] for v in probs}
     for v, p in probs.items():          # warm-up
         capi.run_timed(p, None, sp, 3, 3)
+    if probs:
+        capi.run_timed(next(iter(probs.values())), None, sp, 0, max(1, args.ramp))
     for _ in range(args.rounds):
         for v, p in probs.items():
             times[v].append(capi.run_timed(p, None, sp, 0, args.iters))
