@@ -226,8 +226,10 @@ __device__ __forceinline__ float fast_gelu(float x)
     const float c1  = (float)(-2.0 * 0.035677f);
     const float c2  = (float)(-2.0 * 0.797885f);
     const float u   = x * (c1 * x * x + c2);
-    const float emu = expf(u);
-    return x / (1.f + emu);
+    // the reference's device form (unary_element_wise_operation.hpp:455-465): low-precision exp and rcp;
+    // exp(u) = exp2(u * log2 e) on the transcendental unit (inf for large u gives rcp(inf) = 0 as it should)
+    const float emu = __builtin_amdgcn_exp2f(u * 1.44269504088896341f);
+    return x * __builtin_amdgcn_rcpf(1.f + emu);
 }
 
 __device__ __forceinline__ float load_d_as_f32(const void* d, int idx, int c_dtype)

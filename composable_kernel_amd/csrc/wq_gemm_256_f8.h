@@ -21,10 +21,15 @@
 // wq_gemm_mfma_256; a K tile is one MFMA deep, so the two MFMA sections of a tile split the 16
 // accumulator row blocks instead of the k-steps:
 //   L0: DMA pieces [0,3) of tile t+2; activation fragments of row blocks 0..7          b
-//   M0: 16 MFMAs (row blocks 0..7); late waves: wait for tile t+1's DMA                b
+//   M0: 16 MFMAs (row blocks 0..7, column block 0 first) with the last 3 of the 8 conversion pieces of
+//       this tile's weights (they complete column block 1's fragment) between the first 8;
+//       late waves: wait for tile t+1's DMA                                            b
 //   L1: DMA pieces [3,6) of tile t+2; activation fragments of row blocks 8..15;
 //       early waves: wait for tile t+1's DMA                                           b
-//   M1: 16 MFMAs (row blocks 8..15) interleaved with the conversion of tile t+1's weights  b
+//   M1: 16 MFMAs (row blocks 8..15); raw weights of tile t+1 read behind the first, conversion
+//       pieces 0..4 of tile t+1 between the last 13                                    b
+// (conversion piece = one 32-bit word of 8 nibbles -> 8 E5M2 bytes, 11 VALU instructions; 3-4 of them
+// fit behind each 32-cycle MFMA)
 #pragma once
 
 #include "wq_gemm_256.h"
@@ -58,9 +63,8 @@ __device__ __forceinline__ int f8_b_swz(int col) { return (col >> 2) & 2; }
 // (w & mask) | magic with the mask in a scalar register
 __device__ __forceinline__ uint32_t and_or_s(uint32_t w, uint32_t mask, uint32_t magic)
 {
-    uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask), "v"(magic));
-    return r;
+    // (mask and magic are opaque register values, see I4F8Consts::init: one v_and_or_b32)
+    return (w & mask) | magic;
 }
 
 struct I4F8Consts
@@ -91,8 +95,9 @@ __device__ __forceinline__ void dequant8_i4_e5m2(int& o0, int& o1, const I4F8Con
     o1                = (int)__builtin_amdgcn_perm(as_u32(t3), as_u32(t2), 0x07050301u);
 }
 
-// VPM: VALU instructions the scheduler is asked to place behind each MFMA of the converting section.
-template <bool STAMP = false, int VPM = 6>
+// (Issuing the LDS-DMA pieces between the MFMAs that carry no conversion work instead of in the load sections
+// was measured 6 % slower: a piece costs an MFMA section 100-130 cycles.)
+template <bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p)
 {
     using T = Mfma256F8;
@@ -208,25 +213,18 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
         for(int nt = 0; nt < NT; ++nt)
             raw[nt] = *(const u4_t*)(sb + b_off[nt]);
     };
-    auto convert = [&](i8v_t(&out)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-        for(int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for(int d = 0; d < 4; ++d)
-            {
-                int o0, o1;
-                dequant8_i4_e5m2(o0, o1, i4c, raw[nt][d]);
-                out[nt][2 * d]     = o0;
-                out[nt][2 * d + 1] = o1;
-            }
-        // pin the conversion to this section: without an opaque use the optimiser sinks it to the MFMAs
-        // that consume it, i.e. into the head of the next tile
-#pragma unroll
-        for(int nt = 0; nt < NT; ++nt)
-            asm volatile(""
-                         : "+v"(out[nt][0]), "+v"(out[nt][1]), "+v"(out[nt][2]), "+v"(out[nt][3]), "+v"(out[nt][4]),
-                           "+v"(out[nt][5]), "+v"(out[nt][6]), "+v"(out[nt][7]));
+    // Conversion piece j (0..7) = 32-bit word j % 4 of raw[j / 4] -> registers 2 (j % 4), +1 of out[j / 4]:
+    // 11 VALU instructions.  The opaque use pins the piece where it is written: without it the optimiser
+    // sinks the arithmetic to the MFMAs that consume it.
+    auto convert_piece = [&](i8v_t(&out)[NT], auto piece) __attribute__((always_inline)) {
+        constexpr int j = decltype(piece)::value, nt = j / 4, d = j % 4;
+        int o0, o1;
+        dequant8_i4_e5m2(o0, o1, i4c, raw[nt][d]);
+        out[nt][2 * d]     = o0;
+        out[nt][2 * d + 1] = o1;
+        asm volatile("" : "+v"(out[nt][2 * d]), "+v"(out[nt][2 * d + 1]));
     };
+    // pieces [0, 5) are converted in M1 (or the prologue), [5, 8) in the first half of the next M0
     auto mfma_one = [&](const i8v_t(&w)[NT], int i, int mt, int nt) __attribute__((always_inline)) {
         i8v_t a;
         a[0] = af[i][0][0], a[1] = af[i][0][1], a[2] = af[i][0][2], a[3] = af[i][0][3];
@@ -239,6 +237,26 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
         for(int j = first; j < last; ++j)
             mfma_one(w, j >> 1, mt_first + (j >> 1), j & 1);
     };
+    // M0 order: all row blocks with column block 0 first, then column block 1 (whose fragment is completed
+    // during the first half); M1 order: row-block major.
+    auto mfma_m0 = [&](const i8v_t(&w)[NT], auto first, auto last) __attribute__((always_inline)) {
+#pragma unroll
+        for(int j = first; j < last; ++j)
+            mfma_one(w, j & 7, j & 7, j >> 3);
+    };
+    // k MFMAs [first, first + k) of `issue`, then one conversion piece, its VALU instructions spread behind the MFMAs
+    auto step = [&](auto issue, i8v_t(&out)[NT], auto first, auto count, auto piece) __attribute__((always_inline)) {
+        constexpr int f = decltype(first)::value, k = decltype(count)::value;
+        issue(std::integral_constant<int, f>{}, std::integral_constant<int, f + k>{});
+        convert_piece(out, piece);
+#pragma unroll
+        for(int i = 0; i < k; ++i)
+        {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (11 + k - 1) / k, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     // MFMAs have no side effects the optimiser knows of, so nothing keeps them from sinking below the
     // section barriers to the next use of their accumulators (which would keep both halves of the
     // activation fragments alive at once).  An opaque use of the accumulators ends the section.
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
             asm volatile("" : "+v"(acc[0][mt_first + i]), "+v"(acc[1][mt_first + i]));
     };
 
-    unsigned long long t_work[4] = {0, 0, 0, 0}, t_wait[4] = {0, 0, 0, 0}, t_a = 0;
+    unsigned long long t_work[4] = {0, 0, 0, 0}, t_wait[4] = {0, 0, 0, 0}, t_sub[2] = {0, 0}, t_a = 0;
     auto sync = [&](auto sec) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -276,7 +294,6 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
     constexpr std::integral_constant<int, 3> kM1{};
     constexpr std::integral_constant<int, 0> k0{};
     constexpr std::integral_constant<int, 1> k1{};
-    constexpr std::integral_constant<int, 4> k4{};
     constexpr std::integral_constant<int, 16> k16{};
 
     if(ntiles > 0)
@@ -292,7 +309,11 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
         __builtin_amdgcn_s_barrier();
 
         read_raw(0);
-        convert(wf);
+        convert_piece(wf, std::integral_constant<int, 0>{});
+        convert_piece(wf, std::integral_constant<int, 1>{});
+        convert_piece(wf, std::integral_constant<int, 2>{});
+        convert_piece(wf, std::integral_constant<int, 3>{});
+        convert_piece(wf, std::integral_constant<int, 4>{});
         __builtin_amdgcn_sched_barrier(0);
         if(late)
             __builtin_amdgcn_s_barrier();
@@ -315,15 +336,41 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
             // L0
             if(more2)
                 stage_part(nxt2, kD_begin, kD_mid);
+            if constexpr(STAMP)
+            {
+                unsigned long long t_x;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_x)::"memory");
+                t_sub[0] += t_x - t_a;
+                __builtin_amdgcn_sched_barrier(0);
+            }
             load_a(cur, 0);
+            if constexpr(STAMP)
+            {
+                unsigned long long t_x;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_memtime %0" : "=s"(t_x)::"memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                t_sub[1] += t_x - t_a;
+                __builtin_amdgcn_sched_barrier(0);
+            }
             sync(kL0);
             // M0
             __builtin_amdgcn_s_setprio(1);
-            mfma_range(w, 0, k0, k16);
+            {
+                // column block 0 for the 8 row blocks, with pieces 5..7 (the rest of column block 1's fragment)
+                auto issue = [&](auto a, auto b) __attribute__((always_inline)) { mfma_m0(w, a, b); };
+                using ic = std::integral_constant<int, 0>;
+                step(issue, wf, ic{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 5>{});
+                step(issue, wf, std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
+                step(issue, wf, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 7>{});
+                mfma_m0(w, std::integral_constant<int, 8>{}, k16);
+            }
             pin_acc(0);
             __builtin_amdgcn_s_setprio(0);
             if(late)
             {
+                // tile t+1 complete; leave what was issued for tile t+2 so far (D0 pieces) in flight
                 if(more2)
                     wait_vmcnt<D0>();
                 else
@@ -350,17 +397,14 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
                 __builtin_amdgcn_sched_barrier(0);
                 read_raw(nxt); // behind the first MFMA: its operand wait must not cover this read
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_range(w, MH, k1, k4);
+                mfma_range(w, MH, k1, std::integral_constant<int, 3>{});
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_range(w, MH, k4, k16);
-                convert(w_next);
-#pragma unroll
-                for(int i = 0; i < 12; ++i)
-                {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x002, 88, 0);
+                auto issue = [&](auto a, auto b) __attribute__((always_inline)) { mfma_range(w, MH, a, b); };
+                step(issue, w_next, std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+                step(issue, w_next, std::integral_constant<int, 6>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+                step(issue, w_next, std::integral_constant<int, 9>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+                step(issue, w_next, std::integral_constant<int, 12>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+                step(issue, w_next, std::integral_constant<int, 14>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
             }
             else
                 mfma_range(w, MH, k0, k16);
@@ -368,9 +412,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
             __builtin_amdgcn_s_setprio(0);
             if constexpr(HAS_NEXT)
             {
-#pragma unroll
-                for(int nt = 0; nt < NT; ++nt)
-                    wf[nt] = wf2[nt];
+                wf[0]    = wf2[0];
+                wf[1][0] = wf2[1][0];
+                wf[1][1] = wf2[1][1];
             }
             sync(kM1);
             cur = nxt;
@@ -391,6 +435,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
                     d[i]     = t_work[i];
                     d[4 + i] = t_wait[i];
                 }
+                d[64]     = t_sub[0]; // L0: DMA pieces issued
+                d[64 + 1] = t_sub[1]; // L0: fragment reads issued (s_memtime itself returns through lgkmcnt)
             }
         }
     }

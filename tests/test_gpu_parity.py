@@ -131,15 +131,20 @@ def test_bf16_int8_golden_generic_all_epilogues(golden_gemm):
         if ep == 0:
             np.testing.assert_array_equal(got, exp)   # same order, truncating store: bit-exact
         else:
-            # FastGelu uses fp32 expf on the device vs double exp on the host: allow one bf16 ulp
+            # FastGelu on the device is the reference's device form (hardware exp2 and rcp,
+            # unary_element_wise_operation.hpp:455-465) vs double exp and a true division on the host: one bf16
+            # ulp, or 1e-6 absolute where the result underflows towards zero (x << 0)
             d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
-            assert d.max() <= 1, d.max()
+            tiny = np.abs(bits_to_f32(got, capi.BF16) - bits_to_f32(exp, capi.BF16)) <= 1e-6
+            assert (d[~tiny] <= 1).all(), d[~tiny].max()
     # row-major B (example/60's layout) through the generic kernel
     brow = np.ascontiguousarray(g["bf16_bcol"].T)
     got = run_fpaintb(g["bf16_a"], brow, g["bf16_s"], M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
                       epilogue=capi.EPI_FASTGELU, b_layout=capi.ROW_MAJOR, ldb=N, expect_kernel=GENERIC)
-    d = np.abs(got.astype(np.int32) - g["bf16_e_row_ep1"].reshape(M, N).astype(np.int32))
-    assert d.max() <= 1
+    exp = g["bf16_e_row_ep1"].reshape(M, N)
+    d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+    tiny = np.abs(bits_to_f32(got, capi.BF16) - bits_to_f32(exp, capi.BF16)) <= 1e-6
+    assert (d[~tiny] <= 1).all()
 
 
 def test_bf16_int8_mfma(port):
