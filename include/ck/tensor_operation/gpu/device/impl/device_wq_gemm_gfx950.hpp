@@ -46,6 +46,7 @@
 #include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
 
 #include "wqgemm.h"
+#include "wqgemm/wq_types.hpp"
 
 namespace ck {
 
@@ -78,6 +79,11 @@ template <>
 struct dtype_of<ck::f8_t>
 {
     static constexpr int value = WQ_F8_FNUZ;
+};
+template <>
+struct dtype_of<ck::wq_f8_e4m3fn_t>
+{
+    static constexpr int value = WQ_F8_E4M3FN;
 };
 template <>
 struct dtype_of<float>
@@ -382,8 +388,12 @@ struct DeviceGemmMultiABD_WeightQuant_gfx950
 // ---------------------------------------------------------------------------------------------
 // E = cde_op( A[M,K] fp8 * B[K,N] int4/int8, D0[N] f32, D1[M] f32 )       multiply_multiply form
 // ---------------------------------------------------------------------------------------------
+// ADataType ck::f8_t (E4M3 FNUZ, the reference's fp8) or ck::wq_f8_e4m3fn_t (OCP E4M3, native to the gfx950
+// matrix core).  The matrix core cannot express three FNUZ encodings (0x7F / 0xFF = +-240 and 0x80 = NaN), so
+// FNUZ data runs on it only with AssumeNoFnuzSpecials = true, by which the caller vouches that the
+// activations hold none of them; otherwise FNUZ data takes the exact (slow) general kernel.
 template <typename ALayout, typename BLayout, typename ELayout, typename ADataType, typename BDataType,
-          typename EDataType, typename CDEElementwiseOperation>
+          typename EDataType, typename CDEElementwiseOperation, bool AssumeNoFnuzSpecials = false>
 struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
     : public DeviceGemmMultipleD<ALayout, BLayout, ck::Tuple<ELayout, ELayout>, ELayout, ADataType, BDataType,
                                  ck::Tuple<float, float>, EDataType, element_wise::PassThrough,
@@ -423,6 +433,7 @@ struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
         p.d0 = p_ds[0], p.d1 = p_ds[1];
         p.epilogue = epilogue();
         p.k_batch  = 1;
+        p.flags    = AssumeNoFnuzSpecials ? WQ_FLAG_F8_NO_SPECIALS : 0;
         return arg;
     }
     static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiplyMultiply_WeightQuant_gfx950"}; }

@@ -31,6 +31,8 @@
 #include <type_traits>
 #include <typeinfo>
 
+#include "wqgemm/wq_types.hpp"
+
 namespace ck {
 
 using index_t      = int32_t;
@@ -90,10 +92,35 @@ inline uint32_t float_to_bits(float f)
 }
 } // namespace detail
 
+// fp8 E4M3 FNUZ -> float: bias 8, 0x80 = NaN, no infinities, subnormals m * 2^-10
+// (include/ck/utility/f8_utils.hpp:186-267, type_convert.hpp:383-396)
+inline float f8_fnuz_to_float(uint8_t b)
+{
+    if(b == 0x80)
+        return detail::bits_to_float(0x7F800001u);
+    const int e   = (b >> 3) & 15, m = b & 7;
+    const float v = e == 0 ? static_cast<float>(m) * 0.0009765625f : __builtin_ldexpf(static_cast<float>(8 + m), e - 11);
+    return (b & 0x80) ? -v : v;
+}
+
+// fp8 E4M3FN (OCP, the gfx950 matrix core's E4M3; not a type of the reference): bias 7, S.1111.111 = NaN
+inline float f8_e4m3fn_to_float(uint8_t b)
+{
+    if((b & 0x7F) == 0x7F)
+        return detail::bits_to_float(0x7FC00000u);
+    const int e   = (b >> 3) & 15, m = b & 7;
+    const float v = e == 0 ? static_cast<float>(m) * 0.001953125f : __builtin_ldexpf(static_cast<float>(8 + m), e - 10);
+    return (b & 0x80) ? -v : v;
+}
+
 template <typename Y, typename X>
 inline Y type_convert(X x)
 {
-    if constexpr(std::is_same_v<Y, bhalf_t> && std::is_same_v<X, float>)
+    if constexpr(std::is_same_v<X, f8_t>)
+        return static_cast<Y>(f8_fnuz_to_float(static_cast<uint8_t>(x)));
+    else if constexpr(std::is_same_v<X, wq_f8_e4m3fn_t>)
+        return static_cast<Y>(f8_e4m3fn_to_float(x.data));
+    else if constexpr(std::is_same_v<Y, bhalf_t> && std::is_same_v<X, float>)
         return static_cast<bhalf_t>(detail::float_to_bits(x) >> 16); // truncation
     else if constexpr(std::is_same_v<Y, float> && std::is_same_v<X, bhalf_t>)
         return detail::bits_to_float(static_cast<uint32_t>(x) << 16);
