@@ -505,6 +505,31 @@ __device__ __forceinline__ float f8_e4m3fn_to_f32(uint8_t x)
     return (x & 0x80) ? -v : v;
 }
 
+// fp8 FNUZ activations -> fp16 (exact: every FNUZ value, NaN included, is an fp16 value), 8 per thread, into a
+// dense [M][K] image; also fills `ones` (N fp16 values 1.0, the unit weight scale of the fp16 GEMM that follows).
+__global__ __launch_bounds__(256) void wq_f8_fnuz_to_f16(const uint8_t* a, int lda, int M, int K, uint16_t* out,
+                                                         uint16_t* ones, int N)
+{
+    const long groups = (long)M * (K / 8);
+    for(long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long)gridDim.x * blockDim.x)
+    {
+        const int m = (int)(g / (K / 8)), k8 = (int)(g % (K / 8));
+        const u2_t raw = *(const u2_t*)(a + (size_t)m * lda + k8 * 8);
+        u4_t o;
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+        {
+            const uint32_t w  = raw[i >> 1] >> (16 * (i & 1));
+            const _Float16 lo = (_Float16)f8_fnuz_to_f32((uint8_t)(w & 0xFF));
+            const _Float16 hi = (_Float16)f8_fnuz_to_f32((uint8_t)((w >> 8) & 0xFF));
+            o[i] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+        }
+        *(u4_t*)(out + (size_t)m * K + k8 * 8) = o;
+    }
+    for(int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
+        ones[n] = 0x3C00;
+}
+
 __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
 {
     const int n = blockIdx.x * 16 + (threadIdx.x & 15);

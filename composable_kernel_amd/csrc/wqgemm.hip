@@ -65,6 +65,7 @@ struct Plan
     int k_per_z   = 0;
     bool partial  = false; // main kernel writes fp32 partial slabs
     bool to_c     = false; // ... directly into p->c (multi-GPU slice) instead of the workspace
+    bool via_f16  = false; // fp8 FNUZ activations: convert to fp16 in the workspace, then the fp16 MFMA kernel
 };
 
 bool is16(int dt) { return dt == WQ_F16 || dt == WQ_BF16; }
@@ -188,6 +189,17 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
        p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
        (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
         plan.route = ROUTE_F8_MFMA256;
+    // FNUZ bytes without that promise: exact in every encoding through an fp16 image of A in the workspace and
+    // the fp16 kernels with a unit weight scale (falls back to the general kernel when no workspace is given).
+    if(p->a_dtype == WQ_F8_FNUZ && plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) &&
+       !plan.partial && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->M % 128 == 0 &&
+       p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
+       (uintptr_t)p->a % 8 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
+    {
+        plan.via_f16 = true;
+        plan.ak      = wq::A_F16;
+        plan.route   = ROUTE_MFMA128;
+    }
     if(plan.route == ROUTE_MFMA128 && p->M % 256 == 0 && p->N % 256 == 0 && p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
@@ -230,11 +242,26 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.a         = p->a;
         gp.b         = p->b;
         gp.scale     = p->scale;
+        gp.lda       = p->lda;
+        if(plan.via_f16)
+        {
+            // workspace = [M][K] fp16 image of A, then N fp16 ones
+            uint16_t* a16  = (uint16_t*)workspace;
+            uint16_t* ones = a16 + (size_t)p->M * p->K;
+            const long groups = (long)p->M * (p->K / 8);
+            int blocks        = (int)((groups + 255) / 256);
+            if(blocks > 8192)
+                blocks = 8192;
+            hipLaunchKernelGGL(wq::wq_f8_fnuz_to_f16, dim3(blocks), dim3(256), 0, s, (const uint8_t*)p->a, p->lda, p->M,
+                               p->K, a16, ones, p->N);
+            gp.a     = a16;
+            gp.scale = ones;
+            gp.lda   = p->K;
+        }
         gp.c         = out;
         gp.M         = p->M;
         gp.N         = p->N;
         gp.K         = p->K;
-        gp.lda       = p->lda;
         gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb;
         gp.ldc       = ld_out;
         gp.k_begin   = plan.k_begin;
@@ -414,6 +441,8 @@ size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
         return 0;
     if(plan.partial && !plan.to_c)
         return (size_t)plan.k_batch * p->M * p->N * sizeof(float);
+    if(plan.via_f16)
+        return ((size_t)p->M * p->K + p->N) * sizeof(uint16_t);
     return 0;
 }
 
@@ -427,6 +456,11 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     if(plan.partial && !plan.to_c && !workspace)
         return fail(WQ_ERR_WORKSPACE, "k_batch = %d needs a workspace of %zu bytes", plan.k_batch,
                     (size_t)plan.k_batch * p->M * p->N * sizeof(float));
+    if(plan.via_f16 && !workspace)
+    {
+        plan.via_f16 = false; // no room for the fp16 image of A: the general kernel is exact as well
+        plan.route   = ROUTE_GENERIC;
+    }
     const int rm = launch_main(p, plan, workspace, s);
     if(rm != WQ_OK)
         return rm;
@@ -508,7 +542,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
     const int rc = make_plan(p, plan);
     if(rc != WQ_OK)
         return rc;
-    snprintf(buf, n, "%s",
+    snprintf(buf, n, "%s%s", plan.via_f16 ? "wq_f8_fnuz_to_f16+" : "",
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"

@@ -5,7 +5,7 @@
 //
 //   example_gemm_multiply_multiply_fp8_int4_gfx950 [verify init time_kernel [M N K [fmt [gelu]]]]
 //     init: 1 integer values (exact check), 2 fp8 bytes of 8 binades (tolerance check)
-//     fmt:  0 FNUZ bytes on the exact general kernel, 1 FNUZ bytes on the fp8 matrix core (the generated data
+//     fmt:  0 FNUZ bytes, any encoding (fp16 image of A in the workspace + fp16 matrix core), 1 FNUZ bytes on the fp8 matrix core (the generated data
 //           holds none of 0x7F / 0xFF / 0x80), 2 E4M3FN bytes on the fp8 matrix core
 #include <iostream>
 #include <random>
@@ -97,6 +97,10 @@ int run(bool do_verification, int init_method, bool time_kernel, ck::index_t M, 
         std::cerr << op.GetTypeString() << " does not support this problem" << std::endl;
         return 0;
     }
+    // workspace, the way the reference's split-K examples hand one over
+    // (example/35_splitK_gemm/run_gemm_splitk_reduce_multi_d_example.inc:254-255)
+    DeviceMem workspace(op.GetWorkSpaceSize(&argument));
+    op.SetWorkSpacePointer(&argument, workspace.GetDeviceBuffer());
     const float ave_time = invoker.Run(argument, StreamConfig{nullptr, time_kernel});
     hip_check_error(hipDeviceSynchronize());
     const std::size_t bytes = m * k + k * n / 2 + sizeof(float) * (m + n) + sizeof(EDataType) * m * n;
@@ -140,7 +144,7 @@ int main(int argc, char* argv[])
     if(argc == 2 || argc == 3 || argc == 5 || argc == 6 || argc > 9)
     {
         std::cerr << "arg1: verification (0=no, 1=yes)\narg2: initialization (1=integer value, 2=fp8 bytes)\n"
-                     "arg3: time kernel (0=no, 1=yes)\narg4 to 6: M, N, K\narg7: 0 FNUZ exact kernel, 1 FNUZ matrix core, "
+                     "arg3: time kernel (0=no, 1=yes)\narg4 to 6: M, N, K\narg7: 0 FNUZ via fp16, 1 FNUZ matrix core, "
                      "2 E4M3FN matrix core\narg8: 1 = FastGelu after the scales\n";
         return 1;
     }

@@ -453,6 +453,12 @@ struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
             MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE, a_op, b_op, cde_op));
     }
     std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    // (M*K + N)*2 bytes for FNUZ activations that are not vouched free of the special encodings: room for the
+    // fp16 image of A (device_base.hpp:60-67 conventions: caller allocates, SetWorkSpacePointer hands it over)
+    size_t GetWorkSpaceSize(const BaseArgument* p_arg) const override
+    {
+        return wqgemm_workspace_bytes(&dynamic_cast<const Argument*>(p_arg)->prob);
+    }
     std::string GetTypeString() const override { return "DeviceGemmMultiplyMultiply_WeightQuant_gfx950<F8, I4x2>"; }
 };
 

@@ -113,7 +113,10 @@ const char* wqgemm_last_error(void);
  *  impl/device_fpAintB_gemm_wmma.hpp:510-597). */
 int wqgemm_is_supported(const wqgemm_problem* p);
 
-/* Bytes of device workspace wqgemm_launch needs: k_batch*M*N*4 when k_batch > 1, else 0.
+/* Bytes of device workspace wqgemm_launch can use: k_batch*M*N*4 when k_batch > 1 (required);
+ * (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
+ * fp16 image of A for the fp16 matrix-core kernel; without it the launch uses the general kernel, which is
+ * just as exact and far slower); else 0.
  * Replaces BaseOperator::GetWorkSpaceSize
  * (device_base.hpp:60; impl/device_gemm_xdl_cshuffle_v3r1.hpp:686-694). */
 size_t wqgemm_workspace_bytes(const wqgemm_problem* p);

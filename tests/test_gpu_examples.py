@@ -55,9 +55,10 @@ def test_reference_example64_source_dropin(init):
 
 @pytest.mark.parametrize("fmt,gelu,init", [(0, 0, 1), (1, 0, 1), (1, 1, 2), (2, 0, 1), (2, 1, 2)])
 def test_fp8_int4_multiply_multiply_example(fmt, gelu, init):
-    """example/65's flow (fp8 A, D0 per column, D1 per row, host ReferenceGemm + check_err): FNUZ bytes on the
-    exact general kernel (fmt 0) and on the fp8 matrix core (fmt 1), E4M3FN bytes on the matrix core (fmt 2)."""
-    size = (256, 256, 256) if fmt == 0 else (512, 768, 1024)
+    """example/65's flow (fp8 A, D0 per column, D1 per row, host ReferenceGemm + check_err): FNUZ bytes through
+    the fp16 image in the workspace (fmt 0) and on the fp8 matrix core (fmt 1), E4M3FN bytes on the matrix core
+    (fmt 2)."""
+    size = (512, 768, 1024)
     r = _run(os.path.join(EX, "example_gemm_multiply_multiply_fp8_int4_gfx950"), 1, init, 1, *size, fmt, gelu)
     assert r.returncode == 0 and "verification: PASS" in r.stdout, r.stdout + r.stderr
-    assert ("Mfma" in r.stdout) == (fmt != 0)
+    assert ("16x16x128_f8f6f4" in r.stdout) == (fmt != 0) and "Mfma" in r.stdout

@@ -281,7 +281,7 @@ def test_f8_mfma_fnuz_vs_checker(port, M, N, K):
         exp = port.gemm_f8_i8_mm(a, q, d0, d1, M, N, K, K, K, N, gelu).reshape(M, N)
         check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
         gen = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=kind, d0=d0, d1=d1,
-                          expect_kernel=GENERIC)
+                          flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
         if not gelu:
             np.testing.assert_array_equal(gen, exp)
     # adversarial set: uniformly random bytes (magnitudes log-uniform over 2^-10 .. 224).  The fp8 matrix core
@@ -294,9 +294,21 @@ def test_f8_mfma_fnuz_vs_checker(port, M, N, K):
     a_abs = np.abs(torch.from_numpy(a).view(torch.float8_e4m3fnuz).to(torch.float64).numpy())
     terms = (a_abs @ np.abs(q.astype(np.float64)).T) * d0[None, :] * d1[:, None]
     assert (np.abs(got.astype(np.float64) - exp) <= 1e-3 + 1e-3 * np.abs(exp) + 2.0 ** -12 * terms).all()
-    # without the caller's promise FNUZ data stays on the exact kernel
-    got = run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0, d1=d1,
-                      expect_kernel=GENERIC)
+    # without the caller's promise FNUZ data is converted to fp16 (exact for every byte) and runs on the fp16
+    # matrix-core kernel: all 256 encodings, +-240 included, within check_err defaults; NaN poisons its row
+    a = rng.integers(0, 256, (M, K)).astype(np.uint8)
+    a[a == 0x80] = 0x7F
+    a[5, 17] = 0x80
+    exp = bits_to_f32(port.gemm_f8_i8_mm(a, q, d0, d1, M, N, K, K, K, N, False).reshape(M, N), capi.F16)
+    ok = np.ones(M, bool)
+    ok[5] = False
+    for flags, tile in ((0, 128), (capi.FLAG_TILE_256, 256)):
+        got = bits_to_f32(run_fpaintb(a, bp, None, M, N, K, a_dtype=capi.F8_FNUZ, epilogue=capi.EPI_MULTIPLY_MULTIPLY,
+                                      d0=d0, d1=d1, flags=flags,
+                                      expect_kernel=f"wq_f8_fnuz_to_f16+wq_gemm_mfma_{tile}"), capi.F16)
+        assert np.isnan(got[5]).all() and np.isnan(exp[5]).all()
+        assert not np.isnan(got[ok]).any()
+        check_err(got[ok], exp[ok], 1e-3, 1e-3)
 
 
 def test_f8_mfma_e4m3fn(port):

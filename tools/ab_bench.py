@@ -71,13 +71,16 @@ def main():
             continue
         probs[v] = p
     times = {v: [] for v in probs}
+    ws_bytes = max([capi.workspace_bytes(p) for p in probs.values()] + [0])
+    ws_t = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    ws = ws_t.data_ptr() if ws_t is not None else None
     for v, p in probs.items():          # warm-up
-        capi.run_timed(p, None, sp, 3, 3)
+        capi.run_timed(p, ws, sp, 3, 3)
     if probs:
-        capi.run_timed(next(iter(probs.values())), None, sp, 0, max(1, args.ramp))
+        capi.run_timed(next(iter(probs.values())), ws, sp, 0, max(1, args.ramp))
     for _ in range(args.rounds):
         for v, p in probs.items():
-            times[v].append(capi.run_timed(p, None, sp, 0, args.iters))
+            times[v].append(capi.run_timed(p, ws, sp, 0, args.iters))
     flops = 2.0 * M * N * K
     for v, ts in times.items():
         med, mn = statistics.median(ts), min(ts)
