@@ -64,7 +64,9 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // Epilogue of an MFMA tile kernel: NT x MT accumulator fragments per wave; fragment (nt, mt) covers
 // rows m_base + 16 mt + (lane & 15), columns n_base + 16 nt + 4 (lane >> 4) .. +3.  The epilogue
 // kind and output type are resolved once, outside the fully unrolled fragment loops.
-template <int KIND, bool BF16, int NT, int MT>
+// RSTEP / CSTEP: row / column distance between consecutive fragments (16, 16 for 16x16 MFMA accumulators;
+// 32, 8 for the register groups of 32x32 accumulators).
+template <int KIND, bool BF16, int NT, int MT, int RSTEP = 16, int CSTEP = 16>
 __device__ __forceinline__ void tile_epilogue_k(const GemmParams& p, const f4_t (&acc)[NT][MT], int m_base,
                                                 int n_base, int fr, int fq)
 {
@@ -72,10 +74,10 @@ __device__ __forceinline__ void tile_epilogue_k(const GemmParams& p, const f4_t 
     for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for(int mt = 0; mt < MT; ++mt)
-            store_c4<KIND, BF16>(p.epi, p.c, p.ldc, acc[nt][mt], m_base + mt * 16 + fr, n_base + nt * 16 + fq * 4);
+            store_c4<KIND, BF16>(p.epi, p.c, p.ldc, acc[nt][mt], m_base + mt * RSTEP + fr, n_base + nt * CSTEP + fq * 4);
 }
 
-template <int NT, int MT>
+template <int NT, int MT, int RSTEP = 16, int CSTEP = 16>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&acc)[NT][MT], int m_base,
                                               int n_base, int fr, int fq)
 {
@@ -86,26 +88,26 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
         for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for(int mt = 0; mt < MT; ++mt)
-                *(f4_t*)(slab + (size_t)(m_base + mt * 16 + fr) * p.ldc + n_base + nt * 16 + fq * 4) = acc[nt][mt];
+                *(f4_t*)(slab + (size_t)(m_base + mt * RSTEP + fr) * p.ldc + n_base + nt * CSTEP + fq * 4) = acc[nt][mt];
         return;
     }
     const bool bf = p.epi.c_dtype == 1;
     switch(p.epi.kind)
     {
     case 1:
-        bf ? tile_epilogue_k<1, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<1, false>(p, acc, m_base, n_base, fr, fq);
+        bf ? tile_epilogue_k<1, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<1, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
     case 2:
-        bf ? tile_epilogue_k<2, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<2, false>(p, acc, m_base, n_base, fr, fq);
+        bf ? tile_epilogue_k<2, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<2, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
     case 3:
-        bf ? tile_epilogue_k<3, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<3, false>(p, acc, m_base, n_base, fr, fq);
+        bf ? tile_epilogue_k<3, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<3, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
     case 4:
-        bf ? tile_epilogue_k<4, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<4, false>(p, acc, m_base, n_base, fr, fq);
+        bf ? tile_epilogue_k<4, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<4, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
     default:
-        bf ? tile_epilogue_k<0, true>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<0, false>(p, acc, m_base, n_base, fr, fq);
+        bf ? tile_epilogue_k<0, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<0, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
     }
 }
@@ -118,7 +120,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
 constexpr int kCTilePitch = 528;
 constexpr int kCTileBytes = 256 * kCTilePitch;
 
-template <int KIND, bool BF16, int NT, int MT>
+template <int KIND, bool BF16, int NT, int MT, int RSTEP = 16, int CSTEP = 16>
 __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, const f4_t (&acc)[NT][MT], uint8_t* lds,
                                                        int m0, int n0, int row_w, int col_w, int fr, int fq,
                                                        int wave, int lane)
@@ -128,7 +130,7 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
 #pragma unroll
         for(int mt = 0; mt < MT; ++mt)
         {
-            const int r = row_w + mt * 16 + fr, c = col_w + nt * 16 + fq * 4;
+            const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
             uint16_t o[4];
 #pragma unroll
             for(int j = 0; j < 4; ++j)
@@ -153,20 +155,20 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
     }
 }
 
-template <int NT, int MT>
+template <int NT, int MT, int RSTEP = 16, int CSTEP = 16>
 __device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t (&acc)[NT][MT], uint8_t* lds, int m0,
                                                  int n0, int row_w, int col_w, int fr, int fq, int wave, int lane)
 {
     if(p.partial || p.direct_store)
     {
-        tile_epilogue<NT, MT>(p, acc, m0 + row_w, n0 + col_w, fr, fq);
+        tile_epilogue<NT, MT, RSTEP, CSTEP>(p, acc, m0 + row_w, n0 + col_w, fr, fq);
         return;
     }
     const bool bf = p.epi.c_dtype == 1;
 #define WQ_EPI_CASE(K)                                                                                              \
     case K:                                                                                                         \
-        bf ? tile256_epilogue_lds_k<K, true>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane)                 \
-           : tile256_epilogue_lds_k<K, false>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);               \
+        bf ? tile256_epilogue_lds_k<K, true, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane) \
+           : tile256_epilogue_lds_k<K, false, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane); \
         break;
     switch(p.epi.kind)
     {
@@ -175,8 +177,8 @@ __device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t
         WQ_EPI_CASE(3)
         WQ_EPI_CASE(4)
     default:
-        bf ? tile256_epilogue_lds_k<0, true>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane)
-           : tile256_epilogue_lds_k<0, false>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);
+        bf ? tile256_epilogue_lds_k<0, true, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane)
+           : tile256_epilogue_lds_k<0, false, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);
         break;
     }
 #undef WQ_EPI_CASE

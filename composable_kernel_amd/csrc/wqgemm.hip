@@ -19,6 +19,7 @@ namespace wq {
 WQ_DECL_256(0, 0) WQ_DECL_256(0, 1) WQ_DECL_256(0, 2) WQ_DECL_256(1, 0) WQ_DECL_256(1, 1) WQ_DECL_256(1, 2)
 #undef WQ_DECL_256
 int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant); // wq_inst_256_f8.hip
+int launch_256_w32(const GemmParams& gp, dim3 grid, hipStream_t s, int ak);    // wq_inst_256_w32.hip
 } // namespace wq
 
 namespace {
@@ -79,7 +80,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_GENERIC | WQ_FLAG_F8_NO_SPECIALS))
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_GENERIC | WQ_FLAG_F8_NO_SPECIALS | WQ_FLAG_MFMA_32X32))
         return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");
@@ -301,7 +302,9 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         {
             const int ls = p->flags; // tuning A/B switches
             int rc;
-            if(plan.ak == wq::A_F16)
+            if((ls & WQ_FLAG_MFMA_32X32) && plan.bk == wq::B_I4P)
+                rc = wq::launch_256_w32(gp, grid, s, plan.ak);
+            else if(plan.ak == wq::A_F16)
                 rc = plan.bk == wq::B_I4P   ? wq::launch_256_0_0(gp, grid, s, ls)
                      : plan.bk == wq::B_U8O ? wq::launch_256_0_1(gp, grid, s, ls)
                                             : wq::launch_256_0_2(gp, grid, s, ls);

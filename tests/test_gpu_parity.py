@@ -507,6 +507,41 @@ def test_tile256_schedule_variants_agree(port, variant):
     check_err(bits_to_f32(base, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize("a_dtype", [capi.F16, capi.BF16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 192), (512, 256, 1024)])
+def test_tile256_mfma_32x32_variant(port, a_dtype, M, N, K):
+    """The 256-tile kernel on v_mfma_f32_32x32x16 (different k-to-lane mapping, accumulator layout, swizzles):
+    bit-exact on integer data, check_err defaults on realistic data, all epilogue kinds and split-K."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K + a_dtype)
+    flags = capi.FLAG_TILE_256 | capi.FLAG_MFMA_32X32
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+
+    def ref(a, s):
+        if a_dtype == capi.F16:
+            return port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+        return port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+
+    a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+    s = cvt(rng.integers(1, 4, N).astype(np.float32))
+    got = run_fpaintb(a, bp, s, M, N, K, a_dtype=a_dtype, flags=flags, expect_kernel=MFMA256)
+    np.testing.assert_array_equal(got, ref(a, s))
+    if K >= 192:
+        got = run_fpaintb(a, bp, s, M, N, K, a_dtype=a_dtype, flags=flags, k_batch=3, expect_kernel=MFMA256)
+        np.testing.assert_array_equal(got, ref(a, s))
+    a = cvt(rng.uniform(-1, 1, (M, K)))
+    s = cvt(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    got = run_fpaintb(a, bp, s, M, N, K, a_dtype=a_dtype, flags=flags, expect_kernel=MFMA256)
+    tol = 1e-3 if a_dtype == capi.F16 else 1e-2
+    check_err(bits_to_f32(got, a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3)
+    # FastGelu epilogue against the default kernel (same epilogue code, different accumulator layout)
+    g1 = run_fpaintb(a, bp, s, M, N, K, a_dtype=a_dtype, flags=flags, epilogue=capi.EPI_FASTGELU, expect_kernel=MFMA256)
+    g0 = run_fpaintb(a, bp, s, M, N, K, a_dtype=a_dtype, flags=capi.FLAG_TILE_256, epilogue=capi.EPI_FASTGELU,
+                     expect_kernel=MFMA256)
+    check_err(bits_to_f32(g1, a_dtype), bits_to_f32(g0, a_dtype), tol, 1e-3)
+
+
 def test_tile256_splitk_and_slices(port):
     rng = np.random.default_rng(77)
     M, N, K = 256, 256, 1024
