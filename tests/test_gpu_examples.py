@@ -62,3 +62,13 @@ def test_fp8_int4_multiply_multiply_example(fmt, gelu, init):
     r = _run(os.path.join(EX, "example_gemm_multiply_multiply_fp8_int4_gfx950"), 1, init, 1, *size, fmt, gelu)
     assert r.returncode == 0 and "verification: PASS" in r.stdout, r.stdout + r.stderr
     assert ("16x16x128_f8f6f4" in r.stdout) == (fmt != 0) and "Mfma" in r.stdout
+
+
+def test_reference_client_example09_source_dropin():
+    """CK's client_example/09_quantization/gemm_quantization.cpp, compiled unmodified, must find the gfx950
+    operator through CK's own DeviceOperationInstanceFactory (the add_device_* symbols come from
+    composable_kernel_amd/ck_instances/) and run it."""
+    r = _run(os.path.join(EX, "_ref_build", "client_gemm_quantization_dropin"))
+    assert r.returncode == 0, r.stderr
+    assert "found 1 instances" in r.stdout
+    assert "Best Perf" in r.stdout and "DeviceGemmQuantization_gfx950" in r.stdout and "Done" in r.stdout
