@@ -30,7 +30,8 @@ FLAG_DIRECT_STORE, FLAG_GROUP8, FLAG_DEQUANT_IN_L, FLAG_GENERIC, FLAG_F8_NO_SPEC
 FLAG_MFMA_32X32 = 4096
 # wq_epilogue
 (EPI_PASSTHROUGH, EPI_FASTGELU, EPI_MULTIPLY_ADD_FASTGELU, EPI_MULTIPLY_MULTIPLY,
- EPI_MULTIPLY_MULTIPLY_FASTGELU, EPI_ACT_MUL_CLAMP) = range(6)
+ EPI_MULTIPLY_MULTIPLY_FASTGELU, EPI_ACT_MUL_CLAMP, EPI_ADD, EPI_ADD_FASTGELU, EPI_MULTIPLY,
+ EPI_MULTIPLY_FASTGELU) = range(10)
 
 # every symbol include/wqgemm.h declares
 EXPORTS = (

@@ -90,6 +90,13 @@ struct ScaleReg<A_BF16>
     }
 };
 
+// 1.0 in the activation type: the weight scale when the caller passes none (scales applied by the epilogue)
+template <int AK>
+__device__ __forceinline__ constexpr uint16_t unit_scale_bits()
+{
+    return AK == A_F16 ? 0x3C00 : 0x3F80;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dequantise the 8 consecutive-k weights one lane feeds to one MFMA (k = 8g .. 8g+7 of one
 // column) into the 4 VGPRs of a 16-bit operand fragment, element j <-> k = 8g + j.
@@ -260,6 +267,12 @@ __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, 
         const float t = x * ((const float*)e.d0)[n];
         return fast_gelu(t * ((const float*)e.d1)[m]);
     }
+    // binary_element_wise_operation.hpp: Add :78-85, AddFastGelu :511-522, Multiply (float x bhalf), MultiplyFastGelu
+    // :578-590 -- the second operand is d0[n] of the output's 16-bit type
+    case 6: return x + load_d_as_f32(e.d0, n, e.c_dtype);
+    case 7: return fast_gelu(x + load_d_as_f32(e.d0, n, e.c_dtype));
+    case 8: return x * load_d_as_f32(e.d0, n, e.c_dtype);
+    case 9: return fast_gelu(x * load_d_as_f32(e.d0, n, e.c_dtype));
     default: return x;
     }
 }
@@ -285,6 +298,14 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
         const float t = x * ((const float*)e.d0)[n];
         return fast_gelu(t * ((const float*)e.d1)[m]);
     }
+    else if constexpr(KIND == 6)
+        return x + load_d_as_f32(e.d0, n, e.c_dtype);
+    else if constexpr(KIND == 7)
+        return fast_gelu(x + load_d_as_f32(e.d0, n, e.c_dtype));
+    else if constexpr(KIND == 8)
+        return x * load_d_as_f32(e.d0, n, e.c_dtype);
+    else if constexpr(KIND == 9)
+        return fast_gelu(x * load_d_as_f32(e.d0, n, e.c_dtype));
     else
         return x;
 }

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
     // the scale of column 16 nt + (l & 15) of the wave's NT * 16 columns)
     ScaleReg<AK> sc[NT];
     {
-        const uint16_t mine = ((const uint16_t*)p.scale)[n0 + col_w + (lane & (NT * 16 - 1))];
+        const uint16_t mine =
+            p.scale ? ((const uint16_t*)p.scale)[n0 + col_w + (lane & (NT * 16 - 1))] : unit_scale_bits<AK>();
 #pragma unroll
         for(int nt = 0; nt < NT; ++nt)
             sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));

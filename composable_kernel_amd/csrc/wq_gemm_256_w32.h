@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256_w32(const GemmParams 
     const int ntiles   = (kz_end - kz_begin) / T::BK;
 
     ScaleReg<AK> sc;
-    sc.set(((const uint16_t*)p.scale)[n0 + col_w + lr]);
+    sc.set(p.scale ? ((const uint16_t*)p.scale)[n0 + col_w + lr] : unit_scale_bits<AK>());
 
     // LDS-DMA sources: buffer resource + running scalar byte offset per piece + 32-bit lane offsets.
     // A piece i of wave w moves rows 8 (4 w + i) .. +7 (lane -> row lane / 8, chunk lane % 8); the swizzle uses

@@ -106,6 +106,18 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
     case 4:
         bf ? tile_epilogue_k<4, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<4, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
+    case 6:
+        bf ? tile_epilogue_k<6, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<6, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
+        break;
+    case 7:
+        bf ? tile_epilogue_k<7, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<7, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
+        break;
+    case 8:
+        bf ? tile_epilogue_k<8, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<8, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
+        break;
+    case 9:
+        bf ? tile_epilogue_k<9, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<9, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
+        break;
     default:
         bf ? tile_epilogue_k<0, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<0, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
@@ -176,6 +188,10 @@ __device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t
         WQ_EPI_CASE(2)
         WQ_EPI_CASE(3)
         WQ_EPI_CASE(4)
+        WQ_EPI_CASE(6)
+        WQ_EPI_CASE(7)
+        WQ_EPI_CASE(8)
+        WQ_EPI_CASE(9)
     default:
         bf ? tile256_epilogue_lds_k<0, true, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane)
            : tile256_epilogue_lds_k<0, false, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     // scale of column 16 nt + (l & 15).
     ScaleReg<AK> sc[4];
     {
-        const uint16_t mine = ((const uint16_t*)p.scale)[n0 + wn * 64 + lane];
+        const uint16_t mine = p.scale ? ((const uint16_t*)p.scale)[n0 + wn * 64 + lane] : unit_scale_bits<AK>();
 #pragma unroll
         for(int nt = 0; nt < 4; ++nt)
             sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
         return;
     }
 
-    const uint16_t sbits = p.scale ? ((const uint16_t*)p.scale)[n] : 0;
+    const uint16_t sbits = p.scale ? ((const uint16_t*)p.scale)[n] : (p.a_dtype == 1 /*WQ_BF16*/ ? 0x3F80 : 0x3C00);
     float acc            = 0.f;
     for(int k = kb; k < ke; ++k)
     {

@@ -142,9 +142,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_UNSUPPORTED, "packed int4 K slices must start on multiples of 8");
     if(is16(p->a_dtype))
     {
-        if(!p->scale)
-            return fail(WQ_ERR_INVALID, "scale must be non-null for 16-bit activations");
-        if(p->scale_dtype != p->a_dtype)
+        if(p->scale && p->scale_dtype != p->a_dtype)
             return fail(WQ_ERR_UNSUPPORTED, "scale dtype must equal the activation dtype");
     }
     if(!slice)
@@ -164,6 +162,13 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     case WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU:
         if(!p->d0 || !p->d1)
             return fail(WQ_ERR_INVALID, "epilogue %d needs d0 and d1", p->epilogue);
+        break;
+    case WQ_EPI_ADD:
+    case WQ_EPI_ADD_FASTGELU:
+    case WQ_EPI_MULTIPLY:
+    case WQ_EPI_MULTIPLY_FASTGELU:
+        if(!p->d0)
+            return fail(WQ_ERR_INVALID, "epilogue %d needs d0", p->epilogue);
         break;
     default: return fail(WQ_ERR_UNSUPPORTED, "epilogue %d is not valid for this dtype", p->epilogue);
     }

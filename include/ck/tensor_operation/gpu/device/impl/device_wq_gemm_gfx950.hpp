@@ -386,12 +386,148 @@ struct DeviceGemmMultiABD_WeightQuant_gfx950
 };
 
 // ---------------------------------------------------------------------------------------------
+// The whole multi-ABD instance family of the reference for weight-quantized B
+// (library/include/ck/library/tensor_operation_instance/gpu/gemm_multi_abd.hpp:24-260):
+//   ScaleOnB = true : Bs = (B0 int8, B1 scale[N]), BOp = Multiply;   CDE = PassThrough | FastGelu (no D),
+//                                                                     Add | AddFastGelu (D0 = bias[N])
+//   ScaleOnB = false: Bs = (B0 int8),              BOp = PassThrough; CDE = Multiply | MultiplyFastGelu
+//                                                                     (D0 = scale[N]), MultiplyAddFastGelu
+//                                                                     (D0 = scale[N], D1 = bias[N])
+// D tensors have lengths (M, N) and stride 0 along M: N values of E's type.  (The reference's MultiplyAdd for bhalf_t,
+// element_wise_operation.hpp:223-231, multiplies and adds the 16-bit patterns as integers; it is not offered.)
+// ---------------------------------------------------------------------------------------------
+namespace wq_detail {
+template <typename T, int N>
+struct repeat_tuple;
+template <typename T>
+struct repeat_tuple<T, 0>
+{
+    using type = ck::Tuple<>;
+};
+template <typename T>
+struct repeat_tuple<T, 1>
+{
+    using type = ck::Tuple<T>;
+};
+template <typename T>
+struct repeat_tuple<T, 2>
+{
+    using type = ck::Tuple<T, T>;
+};
+
+template <bool ScaleOnB, typename CDE>
+constexpr int multi_abd_epilogue()
+{
+    namespace ew = ck::tensor_operation::element_wise;
+    if constexpr(ScaleOnB)
+    {
+        if constexpr(std::is_same_v<CDE, ew::PassThrough>)
+            return WQ_EPI_PASSTHROUGH;
+        else if constexpr(std::is_same_v<CDE, ew::FastGelu>)
+            return WQ_EPI_FASTGELU;
+        else if constexpr(std::is_same_v<CDE, ew::Add>)
+            return WQ_EPI_ADD;
+        else if constexpr(std::is_same_v<CDE, ew::AddFastGelu>)
+            return WQ_EPI_ADD_FASTGELU;
+        else
+            return -1;
+    }
+    else
+    {
+        if constexpr(std::is_same_v<CDE, ew::Multiply>)
+            return WQ_EPI_MULTIPLY;
+        else if constexpr(std::is_same_v<CDE, ew::MultiplyFastGelu>)
+            return WQ_EPI_MULTIPLY_FASTGELU;
+        else if constexpr(std::is_same_v<CDE, ew::MultiplyAddFastGelu>)
+            return WQ_EPI_MULTIPLY_ADD_FASTGELU;
+        else
+            return -1;
+    }
+}
+constexpr int num_d_of(int epilogue)
+{
+    return epilogue == WQ_EPI_PASSTHROUGH || epilogue == WQ_EPI_FASTGELU ? 0 : (epilogue == WQ_EPI_MULTIPLY_ADD_FASTGELU ? 2 : 1);
+}
+} // namespace wq_detail
+
+template <typename A0Layout, typename B0Layout, typename ELayout, typename A0DataType, typename B0DataType,
+          typename EDataType, bool ScaleOnB, typename CDEElementwiseOperation,
+          int NumB = ScaleOnB ? 2 : 1,
+          int NumD = wq_detail::num_d_of(wq_detail::multi_abd_epilogue<ScaleOnB, CDEElementwiseOperation>())>
+struct DeviceGemmMultiABD_gfx950
+    : public DeviceGemmMultipleABD<
+          ck::Tuple<A0Layout>, typename wq_detail::repeat_tuple<B0Layout, NumB>::type,
+          typename wq_detail::repeat_tuple<ck::tensor_layout::gemm::RowMajor, NumD>::type, ELayout, ck::Tuple<A0DataType>,
+          std::conditional_t<ScaleOnB, ck::Tuple<B0DataType, A0DataType>, ck::Tuple<B0DataType>>,
+          typename wq_detail::repeat_tuple<EDataType, NumD>::type, EDataType, element_wise::PassThrough,
+          std::conditional_t<ScaleOnB, element_wise::Multiply, element_wise::PassThrough>, CDEElementwiseOperation>
+{
+    using Argument    = wq_detail::Argument;
+    using Invoker     = wq_detail::Invoker;
+    using PassThrough = element_wise::PassThrough;
+    using BOp         = std::conditional_t<ScaleOnB, element_wise::Multiply, element_wise::PassThrough>;
+    static constexpr int kEpilogue = wq_detail::multi_abd_epilogue<ScaleOnB, CDEElementwiseOperation>();
+    static_assert(kEpilogue >= 0, "unsupported CDE element-wise operation for this B form");
+
+    static Argument MakeArgument(std::array<const void*, 1> p_as, std::array<const void*, NumB> p_bs,
+                                 std::array<const void*, NumD> p_ds, void* p_e, index_t M, index_t N, index_t K,
+                                 std::array<index_t, 1> StrideAs, std::array<index_t, NumB> StrideBs,
+                                 std::array<index_t, NumD>, index_t StrideE, PassThrough, BOp, CDEElementwiseOperation)
+    {
+        Argument arg;
+        wqgemm_problem& p = arg.prob;
+        p.a_dtype         = wq_detail::dtype_of<A0DataType>::value;
+        p.b_dtype         = wq_detail::dtype_of<B0DataType>::value;
+        p.scale_dtype     = p.a_dtype;
+        p.c_dtype         = wq_detail::dtype_of<EDataType>::value;
+        p.a_layout        = wq_detail::layout_of<A0Layout>();
+        p.b_layout        = wq_detail::layout_of<B0Layout>();
+        p.c_layout        = wq_detail::layout_of<ELayout>();
+        p.M = M, p.N = N, p.K = K;
+        p.lda = StrideAs[0], p.ldb = StrideBs[0], p.ldc = StrideE;
+        p.a = p_as[0], p.b = p_bs[0], p.c = p_e;
+        if constexpr(ScaleOnB)
+            p.scale = p_bs[1]; // lengths (K, N), stride 0 along K: N values
+        if constexpr(NumD >= 1)
+            p.d0 = p_ds[0];
+        if constexpr(NumD >= 2)
+            p.d1 = p_ds[1];
+        p.epilogue = kEpilogue;
+        p.k_batch  = 1;
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiABD_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument>
+    MakeArgumentPointer(std::array<const void*, 1> p_as, std::array<const void*, NumB> p_bs,
+                        std::array<const void*, NumD> p_ds, void* p_e, index_t M, index_t N, index_t K,
+                        std::array<index_t, 1> StrideAs, std::array<index_t, NumB> StrideBs,
+                        std::array<index_t, NumD> StrideDs, index_t StrideE, PassThrough a_op, BOp b_op,
+                        CDEElementwiseOperation cde_op) override
+    {
+        return std::make_unique<Argument>(MakeArgument(p_as, p_bs, p_ds, p_e, M, N, K, StrideAs, StrideBs, StrideDs,
+                                                       StrideE, a_op, b_op, cde_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    std::string GetTypeString() const override
+    {
+        return std::string("DeviceGemmMultiABD_gfx950<BF16, I8, ") + (ScaleOnB ? "MultiplyOnB" : "ScaleInEpilogue") +
+               ", Epilogue" + std::to_string(kEpilogue) + ">";
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // E = cde_op( A[M,K] fp8 * B[K,N] int4/int8, D0[N] f32, D1[M] f32 )       multiply_multiply form
 // ---------------------------------------------------------------------------------------------
 // ADataType ck::f8_t (E4M3 FNUZ, the reference's fp8) or ck::wq_f8_e4m3fn_t (OCP E4M3, native to the gfx950
 // matrix core).  The matrix core cannot express three FNUZ encodings (0x7F / 0xFF = +-240 and 0x80 = NaN), so
 // FNUZ data runs on it only with AssumeNoFnuzSpecials = true, by which the caller vouches that the
-// activations hold none of them; otherwise FNUZ data takes the exact (slow) general kernel.
+// activations hold none of them; otherwise FNUZ data goes through an fp16 image in the workspace (GetWorkSpaceSize)
+// or, without a workspace, the exact general kernel.
 template <typename ALayout, typename BLayout, typename ELayout, typename ADataType, typename BDataType,
           typename EDataType, typename CDEElementwiseOperation, bool AssumeNoFnuzSpecials = false>
 struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950

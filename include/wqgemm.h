@@ -56,7 +56,11 @@ typedef enum wq_epilogue
     WQ_EPI_MULTIPLY_ADD_FASTGELU      = 2, /* element_wise_operation.hpp:277-295; d0[n], d1[n] of C's type */
     WQ_EPI_MULTIPLY_MULTIPLY          = 3, /* element_wise_operation.hpp:252-275; d0[n], d1[m] float       */
     WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU = 4, /* FastGelu(c*d0[n]*d1[m]); d0, d1 float                        */
-    WQ_EPI_ACT_MUL_CLAMP              = 5  /* quantization_operation.hpp:24-66; requant_scale, int8 out    */
+    WQ_EPI_ACT_MUL_CLAMP              = 5, /* quantization_operation.hpp:24-66; requant_scale, int8 out    */
+    WQ_EPI_ADD                        = 6, /* binary_element_wise_operation.hpp:78-85: c + d0[n]; d0 of C's type */
+    WQ_EPI_ADD_FASTGELU               = 7, /* binary_element_wise_operation.hpp:511-522: FastGelu(c + d0[n])     */
+    WQ_EPI_MULTIPLY                   = 8, /* binary_element_wise_operation.hpp Multiply<C>(float, C): c * d0[n] */
+    WQ_EPI_MULTIPLY_FASTGELU          = 9  /* binary_element_wise_operation.hpp:578-590: FastGelu(c * d0[n])     */
 } wq_epilogue;
 
 /* wqgemm_problem.flags */
@@ -84,7 +88,7 @@ typedef struct wqgemm_problem
     int32_t lda, ldb, ldc;
     const void* a;
     const void* b;
-    const void* scale; /* N values of scale_dtype (lengths (K,N), strides (0,1)); NULL when the epilogue carries the scales */
+    const void* scale; /* N values of scale_dtype (lengths (K,N), strides (0,1)); NULL = unit scale: the epilogue carries the scales */
     void* c;
     int32_t epilogue; /* wq_epilogue */
     float requant_scale;

@@ -196,6 +196,16 @@ struct Multiply
     }
 };
 
+// y = x0 + x1 in fp32 (binary_element_wise_operation.hpp:12-115)
+struct Add
+{
+    template <typename Y, typename X0, typename X1>
+    void operator()(Y& y, const X0& x0, const X1& x1) const
+    {
+        y = ck::type_convert<Y>(ck::type_convert<float>(x0) + ck::type_convert<float>(x1));
+    }
+};
+
 struct FastGelu
 {
     // host form: u = x (c1 x^2 + c2), y = x / (1 + exp(u))
@@ -208,6 +218,28 @@ struct FastGelu
         const float u   = xf * (c1 * xf * xf + c2);
         const float emu = static_cast<float>(std::exp(static_cast<double>(u)));
         y               = ck::type_convert<Y>(xf / (1.f + emu));
+    }
+};
+
+// e = FastGelu(c + d) / FastGelu(c * d) in fp32 (binary_element_wise_operation.hpp:462-590)
+struct AddFastGelu
+{
+    template <typename E, typename C, typename D>
+    void operator()(E& e, const C& c, const D& d) const
+    {
+        float y = 0;
+        FastGelu{}(y, ck::type_convert<float>(c) + ck::type_convert<float>(d));
+        e = ck::type_convert<E>(y);
+    }
+};
+struct MultiplyFastGelu
+{
+    template <typename E, typename C, typename D>
+    void operator()(E& e, const C& c, const D& d) const
+    {
+        float y = 0;
+        FastGelu{}(y, ck::type_convert<float>(c) * ck::type_convert<float>(d));
+        e = ck::type_convert<E>(y);
     }
 };
 

@@ -84,7 +84,7 @@ class Checker:
         self._fpaintb = sig("fpAintB_gemm_f16", None, [_u16p, _i8p, _u16p, _u16p] + [C.c_int] * 6 + tail)
         self._i8 = sig("gemm_i8_requant", None, [_i8p, _i8p, _i8p] + [C.c_int] * 6 + [C.c_float] + tail)
         self._bf16 = sig("gemm_bf16_i8", None,
-                         [_u16p, _i8p, _u16p, _u16p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p] + tail)
+                         [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p] + tail)
         self._f8 = sig("gemm_f8_i8_mm", None, [_u8p, _i8p, _f32p, _f32p, _u16p] + [C.c_int] * 7 + tail)
         if self._threaded:
             self._partial = sig("fpAintB_gemm_f16_partial", None,
@@ -130,7 +130,8 @@ class Checker:
         e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.uint16)
         p0 = d0.ctypes.data if d0 is not None else None
         p1 = d1.ctypes.data if d1 is not None else None
-        self._bf16(a.ravel(), b0.ravel(), b1, e, M, N, K, lda, b_sk, b_sn, lde, epilogue, p0, p1,
+        pb1 = np.ascontiguousarray(b1, np.uint16).ctypes.data if b1 is not None else None  # None: B = PassThrough(b0)
+        self._bf16(a.ravel(), b0.ravel(), pb1, e, M, N, K, lda, b_sk, b_sn, lde, epilogue, p0, p1,
                    *self._t(nthreads))
         return e
 

@@ -201,7 +201,9 @@ void ckref_gemm_i8_requant(const int8_t* a, const int8_t* b, int8_t* e, int M, i
 // example/60 verify path: b = Multiply(b0 int8, b1 bhalf scale[n]); c = ReferenceGemm<bhalf,
 // bhalf, float, float, PT,PT,PT>; e = epilogue(c).  B element (k,n) at k*b_sk + n*b_sn.
 // epilogue: 0 PassThrough (float->bhalf), 1 FastGelu<bhalf,float>,
-//           2 MultiplyAddFastGelu with d0[n], d1[n] bhalf (stride-0 rows).
+//           2 MultiplyAddFastGelu with d0[n], d1[n] bhalf (stride-0 rows),
+//           3 Add, 4 AddFastGelu, 5 Multiply, 6 MultiplyFastGelu with d0[n] bhalf (the multi-ABD instance family).
+// b1 == nullptr: B = PassThrough(b0) (the "multiply" instances).
 void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1, uint16_t* e,
                         int M, int N, int K, int lda, int b_sk, int b_sn, int lde, int epilogue,
                         const uint16_t* d0, const uint16_t* d1)
@@ -211,7 +213,12 @@ void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1,
     Tensor<bhalf_t> tb(desc2(K, N, b_sk, b_sn));
     for(int n = 0; n < N; ++n)
         for(int k = 0; k < K; ++k)
-            ew::Multiply{}(tb(k, n), tb0(k, n), bhalf_t(b1[n]));
+        {
+            if(b1)
+                ew::Multiply{}(tb(k, n), tb0(k, n), bhalf_t(b1[n]));
+            else
+                PT{}(tb(k, n), tb0(k, n));
+        }
     Tensor<float> tc(desc2(M, N, N, 1));
     using Ref =
         ck::tensor_operation::host::ReferenceGemm<bhalf_t, bhalf_t, float, float, PT, PT, PT>;
@@ -226,8 +233,16 @@ void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1,
                 PT{}(y, tc(m, n));
             else if(epilogue == 1)
                 ew::FastGelu{}(y, tc(m, n));
-            else
+            else if(epilogue == 2)
                 ew::MultiplyAddFastGelu{}(y, tc(m, n), bhalf_t(d0[n]), bhalf_t(d1[n]));
+            else if(epilogue == 3)
+                ew::Add{}(y, tc(m, n), bhalf_t(d0[n]));
+            else if(epilogue == 4)
+                ew::AddFastGelu{}(y, tc(m, n), bhalf_t(d0[n]));
+            else if(epilogue == 5)
+                ew::Multiply{}(y, tc(m, n), bhalf_t(d0[n]));
+            else
+                ew::MultiplyFastGelu{}(y, tc(m, n), bhalf_t(d0[n]));
             e[static_cast<size_t>(m) * lde + n] = y;
         }
 }

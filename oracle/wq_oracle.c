@@ -416,7 +416,14 @@ void wqo_gemm_i8_requant(const int8_t* a, const int8_t* b, int8_t* e, int M, int
  *   b(k,n) = Multiply(b0(k,n) int8, b1(n) bhalf)               (truncated to bhalf)
  *   c(m,n) = ReferenceGemm<bhalf,bhalf,float,float,PT,PT,PT>   (fp32, k ascending)
  *   e(m,n) = epilogue(c): 0 PassThrough, 1 FastGelu<bhalf,float>, 2 MultiplyAddFastGelu with
- *            per-column bhalf d0[n], d1[n]  (example/60 ..._multiply_bias_fastgelu_...:245-266).
+ *            per-column bhalf d0[n], d1[n]  (example/60 ..._multiply_bias_fastgelu_...:245-266),
+ *            and the binary functors of the multi-ABD instance family with per-column bhalf d0[n]
+ *            (library/include/ck/library/tensor_operation_instance/gpu/gemm_multi_abd.hpp:24-260):
+ *            3 Add<bhalf>(float, bhalf)               binary_element_wise_operation.hpp:78-85
+ *            4 AddFastGelu<bhalf,float,bhalf>         binary_element_wise_operation.hpp:511-522
+ *            5 Multiply<bhalf>(float, bhalf)          binary_element_wise_operation.hpp:180-188
+ *            6 MultiplyFastGelu<bhalf,float,bhalf>    binary_element_wise_operation.hpp:578-590
+ *   b1 == NULL: the "multiply" instances, B = PassThrough(b0) (int8 -> bhalf, exact), scale in the epilogue.
  * B element (k,n) at k*b_sk + n*b_sn. */
 typedef struct
 {
@@ -435,8 +442,8 @@ static void bf16_i8_mn(void* p, int m, int n)
     for(int k = 0; k < x->K; ++k)
     {
         const float va = wqo_bf16_to_f32(x->a[(size_t)m * x->lda + k]);
-        const float vb = wqo_bf16_to_f32(
-            wqo_multiply_bf16(x->b0[(size_t)k * x->b_sk + (size_t)n * x->b_sn], x->b1[n]));
+        const int8_t q = x->b0[(size_t)k * x->b_sk + (size_t)n * x->b_sn];
+        const float vb = x->b1 ? wqo_bf16_to_f32(wqo_multiply_bf16(q, x->b1[n])) : (float)q;
         acc += va * vb;
     }
     uint16_t y;
@@ -444,8 +451,16 @@ static void bf16_i8_mn(void* p, int m, int n)
         y = wqo_f32_to_bf16(acc);
     else if(x->epilogue == 1)
         y = wqo_f32_to_bf16(wqo_fastgelu(acc));
-    else
+    else if(x->epilogue == 2)
         y = wqo_multiply_add_fastgelu_bf16(acc, x->d0[n], x->d1[n]);
+    else if(x->epilogue == 3)
+        y = wqo_f32_to_bf16(acc + wqo_bf16_to_f32(x->d0[n]));
+    else if(x->epilogue == 4)
+        y = wqo_f32_to_bf16(wqo_fastgelu(acc + wqo_bf16_to_f32(x->d0[n])));
+    else if(x->epilogue == 5)
+        y = wqo_f32_to_bf16(acc * wqo_bf16_to_f32(x->d0[n]));
+    else
+        y = wqo_f32_to_bf16(wqo_fastgelu(acc * wqo_bf16_to_f32(x->d0[n])));
     x->e[(size_t)m * x->lde + n] = y;
 }
 

@@ -149,6 +149,12 @@ def gemm_cases(ref) -> dict:
     for ep in (0, 1, 2):
         out[f"bf16_e_col_ep{ep}"] = ref.gemm_bf16_i8(a, bcol, s, M, N, K, K, 1, K, N, ep, d0, d1)
     out["bf16_e_row_ep1"] = ref.gemm_bf16_i8(a, brow, s, M, N, K, K, N, 1, N, 1, d0, d1)
+    # the binary epilogues of the multi-ABD instance family (3 Add, 4 AddFastGelu, 5 Multiply, 6 MultiplyFastGelu),
+    # with Multiply on B (b1 = s) and for the "multiply" instances (b1 absent, row-major B as in client_example/30)
+    for ep in (3, 4, 5, 6):
+        out[f"bf16_e_col_ep{ep}"] = ref.gemm_bf16_i8(a, bcol, s, M, N, K, K, 1, K, N, ep, d0, d1)
+    for ep in (0, 2, 5, 6):
+        out[f"bf16_mul_e_row_ep{ep}"] = ref.gemm_bf16_i8(a, brow, None, M, N, K, K, N, 1, N, ep, s, d1)
 
     # ---- fp8 (FNUZ bytes) A x int4-range B + MultiplyMultiply (+FastGelu) (config C5, small) --
     M, N, K = 48, 64, 128

@@ -72,3 +72,13 @@ def test_reference_client_example09_source_dropin():
     assert r.returncode == 0, r.stderr
     assert "found 1 instances" in r.stdout
     assert "Best Perf" in r.stdout and "DeviceGemmQuantization_gfx950" in r.stdout and "Done" in r.stdout
+
+
+@pytest.mark.parametrize("name", ["gemm_xdl_bf16_i8", "gemm_bias_xdl_bf16_i8", "gemm_bias_fastgelu_xdl_bf16_i8",
+                                  "gemm_xdl_gelu_bf16_i8", "gemm_xdl_multiply_bf16_i8"])
+def test_reference_client_example30_sources_dropin(name):
+    """CK's client_example/30_gemm_bf16Aint8B sources, compiled unmodified, find the gfx950 bf16 x int8 operators
+    through CK's own multi-ABD instance factory (add_device_* symbols from composable_kernel_amd/ck_instances/)."""
+    r = _run(os.path.join(EX, "_ref_build", f"client30_{name}_dropin"))
+    assert r.returncode == 0, r.stderr
+    assert "found 1 instances" in r.stdout and "Best Perf" in r.stdout and "DeviceGemmMultiABD_gfx950" in r.stdout

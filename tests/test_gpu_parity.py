@@ -147,6 +147,53 @@ def test_bf16_int8_golden_generic_all_epilogues(golden_gemm):
     assert (d[~tiny] <= 1).all()
 
 
+def test_bf16_int8_multi_abd_family_golden(golden_gemm):
+    """The binary epilogues of the multi-ABD instance family on the golden case: Multiply on B with Add /
+    AddFastGelu / Multiply / MultiplyFastGelu, and the "multiply" instances (no scale on B, row-major B)."""
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    a, s, d0, d1 = g["bf16_a"], g["bf16_s"], g["bf16_d0"], g["bf16_d1"]
+    kinds = {3: capi.EPI_ADD, 4: capi.EPI_ADD_FASTGELU, 5: capi.EPI_MULTIPLY, 6: capi.EPI_MULTIPLY_FASTGELU,
+             0: capi.EPI_PASSTHROUGH, 2: capi.EPI_MULTIPLY_ADD_FASTGELU}
+
+    def same(got, exp, gelu):
+        exp = exp.reshape(M, N)
+        if not gelu:
+            np.testing.assert_array_equal(got, exp)
+            return
+        d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+        tiny = np.abs(bits_to_f32(got, capi.BF16) - bits_to_f32(exp, capi.BF16)) <= 1e-6
+        assert (d[~tiny] <= 1).all()
+
+    for ep in (3, 4, 5, 6):
+        got = run_fpaintb(a, g["bf16_bcol"], s, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=kinds[ep], d0=d0,
+                          expect_kernel=GENERIC)
+        same(got, g[f"bf16_e_col_ep{ep}"], ep in (4, 6))
+    brow = np.ascontiguousarray(g["bf16_bcol"].T)
+    for ep in (0, 2, 5, 6):
+        got = run_fpaintb(a, brow, None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=kinds[ep], d0=s, d1=d1,
+                          b_layout=capi.ROW_MAJOR, ldb=N, expect_kernel=GENERIC)
+        same(got, g[f"bf16_mul_e_row_ep{ep}"], ep in (2, 6))
+
+
+def test_bf16_int8_multi_abd_family_mfma(port):
+    """Same family on the matrix-core kernels (tile-aligned, K-contiguous B), against the CPU checker."""
+    rng = np.random.default_rng(30)
+    M, N, K = 256, 256, 192
+    q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    a = bf16_bits(rng.uniform(-1, 1, (M, K)))
+    s = bf16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    d1 = bf16_bits(rng.uniform(-0.5, 0.5, N))
+    for flags, kern in ((0, MFMA), (capi.FLAG_TILE_256, MFMA256)):
+        for ep, kind, with_scale in ((3, capi.EPI_ADD, True), (4, capi.EPI_ADD_FASTGELU, True), (5, capi.EPI_MULTIPLY, False),
+                                     (6, capi.EPI_MULTIPLY_FASTGELU, False), (2, capi.EPI_MULTIPLY_ADD_FASTGELU, False)):
+            d0 = d1 if with_scale else s
+            got = run_fpaintb(a, q, s if with_scale else None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=kind,
+                              d0=d0, d1=d1, flags=flags, expect_kernel=kern)
+            exp = port.gemm_bf16_i8(a, q, s if with_scale else None, M, N, K, K, 1, K, N, ep, d0, d1).reshape(M, N)
+            check_err(bits_to_f32(got, capi.BF16), bits_to_f32(exp, capi.BF16), 1e-2, 1e-3)
+
+
 def test_bf16_int8_mfma(port):
     rng = np.random.default_rng(5)
     M, N, K = 256, 256, 512

@@ -137,6 +137,13 @@ def test_bf16_i8_cases(port, golden_gemm):
     brow = np.ascontiguousarray(bcol.T)
     got = port.gemm_bf16_i8(a, brow, s, M, N, K, K, N, 1, N, 1, d0, d1)
     np.testing.assert_array_equal(got, g["bf16_e_row_ep1"])
+    # binary epilogues of the multi-ABD instance family, and the "multiply" instances (no Multiply on B)
+    for ep in (3, 4, 5, 6):
+        got = port.gemm_bf16_i8(a, bcol, s, M, N, K, K, 1, K, N, ep, d0, d1)
+        np.testing.assert_array_equal(got, g[f"bf16_e_col_ep{ep}"], err_msg=f"epilogue {ep}")
+    for ep in (0, 2, 5, 6):
+        got = port.gemm_bf16_i8(a, brow, None, M, N, K, K, N, 1, N, ep, s, d1)
+        np.testing.assert_array_equal(got, g[f"bf16_mul_e_row_ep{ep}"], err_msg=f"multiply instance, epilogue {ep}")
 
 
 def test_f8_i4_multiply_multiply(port, golden_gemm):

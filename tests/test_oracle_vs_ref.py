@@ -47,9 +47,11 @@ def test_bf16_and_f8_random(port, ref):
     b = rng.integers(-128, 128, (N, K)).astype(np.int8)
     d0 = (rng.uniform(0.5, 1.5, N).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
     d1 = (rng.uniform(-0.5, 0.5, N).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
-    for ep in (0, 1, 2):
+    for ep in (0, 1, 2, 3, 4, 5, 6):
         np.testing.assert_array_equal(port.gemm_bf16_i8(a, b, s, M, N, K, K, 1, K, N, ep, d0, d1),
                                       ref.gemm_bf16_i8(a, b, s, M, N, K, K, 1, K, N, ep, d0, d1))
+        np.testing.assert_array_equal(port.gemm_bf16_i8(a, b, None, M, N, K, K, 1, K, N, ep, d0, d1),
+                                      ref.gemm_bf16_i8(a, b, None, M, N, K, K, 1, K, N, ep, d0, d1))
     a8 = rng.integers(0, 256, (M, K)).astype(np.uint8)
     a8[(a8 == 0x80)] = 0
     b4 = rng.integers(-8, 8, (N, K)).astype(np.int8)
