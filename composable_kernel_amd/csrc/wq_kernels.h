@@ -523,6 +523,39 @@ __device__ __forceinline__ float f8_e4m3fn_to_f32(uint8_t x)
     return (x & 0x80) ? -v : v;
 }
 
+// 8-bit weights (K, N) row-major (N contiguous, ld = ldb) -> (N, K) with K contiguous, the operand order of the
+// matrix-core kernels.  64 x 64 byte tiles through LDS; K and N are multiples of 64.
+__global__ __launch_bounds__(256) void wq_transpose_b8(const uint8_t* b, int ldb, int K, int N, uint8_t* out)
+{
+    __shared__ uint8_t tile[64][64 + 4];
+    const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int t  = threadIdx.x;
+    // read: thread t -> row k = t / 4 (+0), 16 bytes at n = 16 (t % 4)
+    {
+        const int k = t >> 2, nq = (t & 3) * 16;
+        const u4_t v = *(const u4_t*)(b + (size_t)(k0 + k) * ldb + n0 + nq);
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+            *(uint32_t*)&tile[k][nq + 4 * i] = v[i];
+    }
+    __syncthreads();
+    // write: thread t -> column n = t / 4, 16 consecutive k starting at 16 (t % 4)
+    {
+        const int n = t >> 2, kq = (t & 3) * 16;
+        u4_t v;
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+        {
+            uint32_t w = 0;
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                w |= (uint32_t)tile[kq + 4 * i + j][n] << (8 * j);
+            v[i] = w;
+        }
+        *(u4_t*)(out + (size_t)(n0 + n) * K + k0 + kq) = v;
+    }
+}
+
 // fp8 FNUZ activations -> fp16 (exact: every FNUZ value, NaN included, is an fp16 value), 8 per thread, into a
 // dense [M][K] image; also fills `ones` (N fp16 values 1.0, the unit weight scale of the fp16 GEMM that follows).
 __global__ __launch_bounds__(256) void wq_f8_fnuz_to_f16(const uint8_t* a, int lda, int M, int K, uint16_t* out,

@@ -66,6 +66,7 @@ struct Plan
     int k_per_z   = 0;
     bool partial  = false; // main kernel writes fp32 partial slabs
     bool to_c     = false; // ... directly into p->c (multi-GPU slice) instead of the workspace
+    bool via_colb = false; // row-major 8-bit B: transpose into the workspace, then the K-contiguous matrix-core kernels
     bool via_f16  = false; // fp8 FNUZ activations: convert to fp16 in the workspace, then the fp16 MFMA kernel
 };
 
@@ -88,10 +89,13 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "bad a_layout");
     if(p->b_layout != WQ_ROW_MAJOR && p->b_layout != WQ_COL_MAJOR)
         return fail(WQ_ERR_INVALID, "bad b_layout");
-    if(p->lda < (p->a_layout == WQ_ROW_MAJOR ? p->K : p->M))
-        return fail(WQ_ERR_INVALID, "lda too small");
-    if(p->ldb < (p->b_layout == WQ_COL_MAJOR ? p->K : p->N))
-        return fail(WQ_ERR_INVALID, "ldb too small");
+    // Input strides below the row length alias rows; the reference's descriptors accept them
+    // (client_example/30_gemm_bf16Aint8B/gemm_xdl_bf16_i8.cpp:82 passes StrideB = K for a row-major (K, N) B), so
+    // they are addressed as given.  The output stride must keep rows apart.
+    if(p->lda <= 0 || p->ldb <= 0)
+        return fail(WQ_ERR_INVALID, "lda and ldb must be positive");
+    if(p->b_dtype == WQ_I4_PACKED && p->ldb < p->K)
+        return fail(WQ_ERR_INVALID, "ldb too small for packed int4 columns");
     if(p->ldc < p->N)
         return fail(WQ_ERR_INVALID, "ldc too small");
     const int kb = p->k_batch <= 0 ? 1 : p->k_batch;
@@ -186,6 +190,17 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
                        ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
     plan.route = tiled && !(p->flags & WQ_FLAG_GENERIC) ? ROUTE_MFMA128 : ROUTE_GENERIC;
+    // 8-bit weights stored (K, N) row-major (the B layout of client_example/30_gemm_bf16Aint8B): the matrix-core
+    // kernels want K contiguous, so the launch first transposes B into the workspace (HBM-bound, 2 K N bytes);
+    // without a workspace the general kernel runs.
+    if(plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) && is16(p->a_dtype) && !plan.partial &&
+       p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_ROW_MAJOR && p->b_dtype != WQ_I4_PACKED && p->M % 128 == 0 &&
+       p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % 16 == 0 && p->ldc % 4 == 0 &&
+       (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0)
+    {
+        plan.via_colb = true;
+        plan.route    = ROUTE_MFMA128;
+    }
     // fp8 activations x packed int4 weights on the fp8 matrix core (scales arrive through the epilogue).
     // FNUZ bytes qualify only when the caller excludes the three encodings E4M3FN cannot express.
     const bool is_f8 = p->a_dtype == WQ_F8_FNUZ || p->a_dtype == WQ_F8_E4M3FN;
@@ -249,6 +264,13 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.b         = p->b;
         gp.scale     = p->scale;
         gp.lda       = p->lda;
+        if(plan.via_colb)
+        {
+            hipLaunchKernelGGL(wq::wq_transpose_b8, dim3(p->N / 64, p->K / 64), dim3(256), 0, s, (const uint8_t*)p->b, p->ldb,
+                               p->K, p->N, (uint8_t*)workspace);
+            gp.b         = workspace;
+            gp.ldb_bytes = p->K;
+        }
         if(plan.via_f16)
         {
             // workspace = [M][K] fp16 image of A, then N fp16 ones
@@ -268,7 +290,8 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.M         = p->M;
         gp.N         = p->N;
         gp.K         = p->K;
-        gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb;
+        if(!plan.via_colb)
+            gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb;
         gp.ldc       = ld_out;
         gp.k_begin   = plan.k_begin;
         gp.k_end     = plan.k_end;
@@ -451,6 +474,8 @@ size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
         return (size_t)plan.k_batch * p->M * p->N * sizeof(float);
     if(plan.via_f16)
         return ((size_t)p->M * p->K + p->N) * sizeof(uint16_t);
+    if(plan.via_colb)
+        return (size_t)p->K * p->N;
     return 0;
 }
 
@@ -464,10 +489,10 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     if(plan.partial && !plan.to_c && !workspace)
         return fail(WQ_ERR_WORKSPACE, "k_batch = %d needs a workspace of %zu bytes", plan.k_batch,
                     (size_t)plan.k_batch * p->M * p->N * sizeof(float));
-    if(plan.via_f16 && !workspace)
+    if((plan.via_f16 || plan.via_colb) && !workspace)
     {
-        plan.via_f16 = false; // no room for the fp16 image of A: the general kernel is exact as well
-        plan.route   = ROUTE_GENERIC;
+        plan.via_f16 = plan.via_colb = false; // no room for the re-laid-out operand: the general kernel takes it as it is
+        plan.route                   = ROUTE_GENERIC;
     }
     const int rm = launch_main(p, plan, workspace, s);
     if(rm != WQ_OK)
@@ -550,7 +575,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
     const int rc = make_plan(p, plan);
     if(rc != WQ_OK)
         return rc;
-    snprintf(buf, n, "%s%s", plan.via_f16 ? "wq_f8_fnuz_to_f16+" : "",
+    snprintf(buf, n, "%s%s", plan.via_f16 ? "wq_f8_fnuz_to_f16+" : (plan.via_colb ? "wq_transpose_b8+" : ""),
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"

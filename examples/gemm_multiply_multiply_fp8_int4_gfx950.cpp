@@ -97,10 +97,14 @@ int run(bool do_verification, int init_method, bool time_kernel, ck::index_t M, 
         std::cerr << op.GetTypeString() << " does not support this problem" << std::endl;
         return 0;
     }
-    // workspace, the way the reference's split-K examples hand one over
-    // (example/35_splitK_gemm/run_gemm_splitk_reduce_multi_d_example.inc:254-255)
-    DeviceMem workspace(op.GetWorkSpaceSize(&argument));
-    op.SetWorkSpacePointer(&argument, workspace.GetDeviceBuffer());
+    // (FNUZ data of unknown content needs scratch for an fp16 image of A; the argument allocated it.  A caller may
+    // instead hand a buffer over, the way the reference's split-K examples do:
+    // example/35_splitK_gemm/run_gemm_splitk_reduce_multi_d_example.inc:254-255)
+    if(std::is_same_v<ADataType, ck::f8_t> && !NoSpecials && init_method == 1)
+    {
+        static DeviceMem workspace(op.GetWorkSpaceSize(&argument));
+        op.SetWorkSpacePointer(&argument, workspace.GetDeviceBuffer());
+    }
     const float ave_time = invoker.Run(argument, StreamConfig{nullptr, time_kernel});
     hip_check_error(hipDeviceSynchronize());
     const std::size_t bytes = m * k + k * n / 2 + sizeof(float) * (m + n) + sizeof(EDataType) * m * n;

@@ -147,7 +147,10 @@ inline bool supported(const wqgemm_problem& prob)
         std::cout << "DeviceOp err: Arch" << std::endl; // the reference's wording for a wrong target
         return false;
     }
-    return wqgemm_is_supported(&prob) != 0;
+    if(wqgemm_is_supported(&prob) != 0)
+        return true;
+    std::cerr << "wqgemm: " << wqgemm_last_error() << std::endl; // why, for the caller's "does not support" line
+    return false;
 }
 
 inline float run(const wqgemm_problem& prob, void* workspace, const StreamConfig& cfg, const char* who)
@@ -179,6 +182,21 @@ inline std::string type_string(const wqgemm_problem& prob)
 struct Argument : public BaseArgument
 {
     wqgemm_problem prob{};
+    // Scratch for the optional operand re-layouts of the engine (fp16 image of FNUZ activations, K-contiguous copy
+    // of row-major 8-bit weights), owned by the argument so that clients which never heard of a workspace
+    // (client_example/30_gemm_bf16Aint8B) still reach the matrix-core kernels.  A workspace handed over with
+    // SetWorkSpacePointer takes precedence; split-K workspaces stay the caller's (device_base.hpp:60-67).
+    std::shared_ptr<void> owned_workspace;
+    void AllocateOptionalWorkspace()
+    {
+        if(prob.k_batch > 1)
+            return;
+        const size_t bytes = wqgemm_workspace_bytes(&prob);
+        void* ptr          = nullptr;
+        if(bytes != 0 && hipMalloc(&ptr, bytes) == hipSuccess)
+            owned_workspace = std::shared_ptr<void>(ptr, [](void* q) { (void)hipFree(q); });
+    }
+    void* Workspace() const { return p_workspace_ ? p_workspace_ : owned_workspace.get(); }
 };
 
 struct Invoker : public BaseInvoker
@@ -186,7 +204,7 @@ struct Invoker : public BaseInvoker
     explicit Invoker(const char* who) : who_(who) {}
     float Run(const Argument& arg, const StreamConfig& cfg = StreamConfig{})
     {
-        return run(arg.prob, arg.p_workspace_, cfg, who_);
+        return run(arg.prob, arg.Workspace(), cfg, who_);
     }
     float Run(const BaseArgument* p_arg, const StreamConfig& cfg = StreamConfig{}) override
     {
@@ -494,6 +512,7 @@ struct DeviceGemmMultiABD_gfx950
             p.d1 = p_ds[1];
         p.epilogue = kEpilogue;
         p.k_batch  = 1;
+        arg.AllocateOptionalWorkspace();
         return arg;
     }
     static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiABD_gfx950"}; }
@@ -570,6 +589,7 @@ struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
         p.epilogue = epilogue();
         p.k_batch  = 1;
         p.flags    = AssumeNoFnuzSpecials ? WQ_FLAG_F8_NO_SPECIALS : 0;
+        arg.AllocateOptionalWorkspace();
         return arg;
     }
     static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiplyMultiply_WeightQuant_gfx950"}; }

@@ -47,7 +47,10 @@ def test_is_supported_and_routes():
     # null pointers / bad sizes are invalid, not crashes
     assert not capi.is_supported(_problem(a=None))
     assert not capi.is_supported(_problem(M=0))
-    assert not capi.is_supported(_problem(lda=100))
+    assert not capi.is_supported(_problem(lda=0))
+    assert not capi.is_supported(_problem(ldc=100))
+    # an input stride below the row length aliases rows (the reference's descriptors allow it): generic kernel
+    assert capi.kernel_name(_problem(lda=100)) == "wq_gemm_generic"
     # C dtype must follow A for the 16-bit paths
     assert not capi.is_supported(_problem(c_dtype=capi.BF16))
     # launching an unsupported problem returns a status, never raises from C

@@ -72,6 +72,7 @@ def test_reference_client_example09_source_dropin():
     assert r.returncode == 0, r.stderr
     assert "found 1 instances" in r.stdout
     assert "Best Perf" in r.stdout and "DeviceGemmQuantization_gfx950" in r.stdout and "Done" in r.stdout
+    assert "does not support" not in r.stdout
 
 
 @pytest.mark.parametrize("name", ["gemm_xdl_bf16_i8", "gemm_bias_xdl_bf16_i8", "gemm_bias_fastgelu_xdl_bf16_i8",
@@ -82,3 +83,4 @@ def test_reference_client_example30_sources_dropin(name):
     r = _run(os.path.join(EX, "_ref_build", f"client30_{name}_dropin"))
     assert r.returncode == 0, r.stderr
     assert "found 1 instances" in r.stdout and "Best Perf" in r.stdout and "DeviceGemmMultiABD_gfx950" in r.stdout
+    assert "does not support" not in r.stdout

@@ -194,6 +194,29 @@ def test_bf16_int8_multi_abd_family_mfma(port):
             check_err(bits_to_f32(got, capi.BF16), bits_to_f32(exp, capi.BF16), 1e-2, 1e-3)
 
 
+@pytest.mark.parametrize("a_dtype", [capi.F16, capi.BF16])
+def test_row_major_b_via_transpose(port, a_dtype):
+    """8-bit weights stored (K, N) row-major: with a workspace the launch transposes them and runs the matrix-core
+    kernel (bit-identical to the K-contiguous call); without one the general kernel gives the checker's result."""
+    rng = np.random.default_rng(60 + a_dtype)
+    M, N, K = 256, 384, 320
+    q = rng.integers(-128, 128, (N, K)).astype(np.int8)      # (N, K): K contiguous
+    brow = np.ascontiguousarray(q.T)                          # (K, N): N contiguous
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+    a = cvt(rng.uniform(-1, 1, (M, K)))
+    s = cvt(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    col = run_fpaintb(a, q, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8, expect_kernel=MFMA)
+    row = run_fpaintb(a, brow, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8, b_layout=capi.ROW_MAJOR, ldb=N,
+                      expect_kernel="wq_transpose_b8+" + MFMA)
+    np.testing.assert_array_equal(row, col)
+    # padded leading dimension and the offset-binary format
+    pad = np.zeros((K, N + 16), np.uint8)
+    pad[:, :N] = (brow.astype(np.int16) + 128).astype(np.uint8)
+    row = run_fpaintb(a, pad, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.U8_OFFSET, b_layout=capi.ROW_MAJOR, ldb=N + 16,
+                      expect_kernel="wq_transpose_b8+" + MFMA)
+    np.testing.assert_array_equal(row, col)
+
+
 def test_bf16_int8_mfma(port):
     rng = np.random.default_rng(5)
     M, N, K = 256, 256, 512
