@@ -298,7 +298,7 @@ struct ReferenceGemm
                         acc += ck::type_convert<AccDataType>(va) * ck::type_convert<AccDataType>(vb);
                     }
                     CDataType vc = 0;
-                    if constexpr(std::is_integral_v<CDataType> && !std::is_same_v<AccDataType, int32_t>)
+                    if constexpr(std::is_same_v<CDataType, int8_t> && !std::is_same_v<AccDataType, int32_t>)
                         arg.c_element_op_(vc, static_cast<int32_t>(acc)); // the int8 functor takes an int32
                     else
                         arg.c_element_op_(vc, acc);

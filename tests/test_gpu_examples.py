@@ -84,3 +84,22 @@ def test_reference_client_example30_sources_dropin(name):
     assert r.returncode == 0, r.stderr
     assert "found 1 instances" in r.stdout and "Best Perf" in r.stdout and "DeviceGemmMultiABD_gfx950" in r.stdout
     assert "does not support" not in r.stdout
+
+
+@pytest.mark.parametrize("args", [
+    ("gemm_fpAintB", 0, 1, 1, 2, 0, 1, 256, 256, 512, -1, -1, -1),
+    ("gemm_fpAintB", 3, 1, 1, 2, 0, 1, 256, 384, 512, -1, -1, -1),
+    ("gemm_fpAintB", 2, 1, 1, 1, 0, 0, 100, 72, 200, -1, -1, -1),
+    ("gemm_splitk", 0, 1, 1, 1, 0, 1, 256, 256, 2048, -1, -1, -1, 4),
+    ("gemm_quantization", 3, 1, 1, 2, 0, 1, 512, 512, 512, -1, -1, -1),
+    ("gemm_multiply_multiply", 8, 1, 1, 2, 0, 1, 256, 256, 512, -1, -1, 0, 0, -1),
+    ("gemm_multiply_multiply", 9, 1, 1, 2, 0, 1, 256, 512, 512, -1, -1, 0, 0, -1),
+    ("gemm_multiply_multiply", 10, 1, 1, 1, 0, 1, 512, 256, 512, -1, -1, 0, 0, -1),
+])
+def test_profiler_cli(args):
+    """ckProfiler-style command line (operation name, data type, layout, verify, init, log, time, sizes, strides)."""
+    r = _run(os.path.join(EX, "example_wq_profiler"), *args)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verification: PASS" in r.stdout
+    if args[6]:
+        assert "Best Perf for datatype" in r.stdout and "TFlops" in r.stdout
