@@ -1,0 +1,72 @@
+"""PyTorch-ROCm front end of the weight-quantized GEMM: a linear layer whose weights live on the GPU in the
+engine's packed formats, and a ``torch.library`` custom operator around the C ABI launch.
+
+PyTorch supplies device memory and the stream; the arithmetic is the HIP kernels behind ``wqgemm_launch``
+(there is no eager fallback: without the library or a GPU the operator raises).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import capi
+from .weights import PackedWeights
+
+_DT = {torch.float16: capi.F16, torch.bfloat16: capi.BF16}
+_EPILOGUES = {"none": capi.EPI_PASSTHROUGH, "fastgelu": capi.EPI_FASTGELU, "add": capi.EPI_ADD,
+              "add_fastgelu": capi.EPI_ADD_FASTGELU}
+
+
+@torch.library.custom_op("wqgemm::fpaintb_linear", mutates_args=())
+def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, bits: int, epilogue: str,
+                   bias: torch.Tensor | None) -> torch.Tensor:
+    """y[m, n] = epilogue( sum_k x[m, k] * dequant(weight[n, k], scale[n]) [, bias[n]] ).
+
+    x (M, K) fp16 / bf16, row-major; weight uint8 (N, K/2) packed int4 (bits = 4) or int8 (N, K) (bits = 8);
+    scale and bias (N,) of x's dtype; epilogue in {"none", "fastgelu", "add", "add_fastgelu"}."""
+    if not x.is_cuda:
+        raise RuntimeError("wqgemm::fpaintb_linear runs on the GPU only")
+    if x.dtype not in _DT or scale.dtype != x.dtype:
+        raise TypeError("x and scale must both be float16 or both bfloat16")
+    if epilogue not in _EPILOGUES:
+        raise ValueError(f"unknown epilogue {epilogue!r}")
+    if (bias is None) != (epilogue in ("none", "fastgelu")):
+        raise ValueError("bias goes with the add / add_fastgelu epilogues only")
+    M, K = x.shape
+    N = scale.shape[0]
+    x = x.contiguous()
+    # the matrix-core kernels take whole 128-row tiles: pad the rows of a ragged batch
+    Mp = (M + 127) // 128 * 128 if (N % 128 == 0 and K % 64 == 0) else M
+    if Mp != M:
+        xp = torch.zeros((Mp, K), dtype=x.dtype, device=x.device)
+        xp[:M] = x
+        x = xp
+    y = torch.empty((Mp, N), dtype=x.dtype, device=x.device)
+    p = capi.fpAintB_problem(x.data_ptr(), weight.data_ptr(), scale.data_ptr(), y.data_ptr(), Mp, N, K,
+                             a_dtype=_DT[x.dtype], b_dtype=capi.I4_PACKED if bits == 4 else capi.I8,
+                             epilogue=_EPILOGUES[epilogue], d0=bias.data_ptr() if bias is not None else None)
+    with torch.cuda.device(x.device):
+        capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+    return y[:M] if Mp != M else y
+
+
+@fpaintb_linear.register_fake
+def _(x, weight, scale, bits, epilogue, bias):
+    return x.new_empty((x.shape[0], scale.shape[0]))
+
+
+class WqLinear(torch.nn.Module):
+    """Inference-only linear layer over packed weights (see ``weights.pack`` / ``weights.load_packed``)."""
+
+    def __init__(self, pw: PackedWeights, bias: torch.Tensor | None = None, epilogue: str = "none", device="cuda"):
+        super().__init__()
+        dt = torch.float16 if pw.scale_dtype == "f16" else torch.bfloat16
+        self.bits, self.in_features, self.out_features = pw.bits, pw.K, pw.N
+        self.register_buffer("weight", torch.from_numpy(pw.weight.copy()).to(device))
+        self.register_buffer("scale", torch.from_numpy(pw.scale.view("int16").copy()).view(dt).to(device))
+        self.register_buffer("bias", None if bias is None else bias.to(device=device, dtype=dt))
+        self.epilogue = ("add" if epilogue == "none" else "add_fastgelu") if bias is not None else epilogue
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lead = x.shape[:-1]
+        y = fpaintb_linear(x.reshape(-1, self.in_features), self.weight, self.scale, self.bits, self.epilogue, self.bias)
+        return y.reshape(*lead, self.out_features)

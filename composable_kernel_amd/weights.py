@@ -1,0 +1,119 @@
+"""Offline weight preparation for the weight-quantized GEMM engine: per-channel symmetric quantisation, packing
+and a small on-disk container.
+
+The reference keeps quantised weights as one int8 (or int4-valued int8) per element and re-encodes them on the
+host right before the GEMM (example/64_fpAintB_gemm/common.hpp:51-83, UnsignedWeightPreprocessor).  Here that step
+is done once, offline: weights are stored K-contiguous per output channel in the engine's device formats
+(``WQ_I4_PACKED``: two offset-binary nibbles per byte in the order documented at ``wqgemm_pack_int4``;
+``WQ_I8``: plain int8), next to their per-channel scales.
+
+Container (``save_packed`` / ``load_packed``): a NumPy ``.npz`` archive with the arrays ``weight`` (uint8 or int8,
+shape (N, K/2) or (N, K)), ``scale`` (uint16 bit patterns of fp16 / bf16, shape (N,)) and the 0-d entries
+``format`` ("wqgemm-weights-1"), ``bits`` (4 or 8), ``scale_dtype`` ("f16" or "bf16"), ``N`` and ``K``.  Loaded with
+``allow_pickle=False``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+FORMAT = "wqgemm-weights-1"
+
+
+@dataclass
+class PackedWeights:
+    weight: np.ndarray      # uint8 (N, K//2) for 4 bits, int8 (N, K) for 8 bits; K contiguous
+    scale: np.ndarray       # uint16 bit patterns, (N,)
+    bits: int
+    scale_dtype: str        # "f16" | "bf16"
+    N: int
+    K: int
+
+    @property
+    def b_dtype(self) -> int:
+        return capi.I4_PACKED if self.bits == 4 else capi.I8
+
+    @property
+    def a_dtype(self) -> int:
+        return capi.F16 if self.scale_dtype == "f16" else capi.BF16
+
+
+def _to_bits(x: np.ndarray, dtype: str) -> np.ndarray:
+    x = np.asarray(x, np.float32)
+    if dtype == "f16":
+        return x.astype(np.float16).view(np.uint16)
+    return (x.view(np.uint32) >> 16).astype(np.uint16)  # bf16 by truncation (include/ck/utility/type_convert.hpp:53-64)
+
+
+def _from_bits(b: np.ndarray, dtype: str) -> np.ndarray:
+    if dtype == "f16":
+        return b.view(np.float16).astype(np.float32)
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def quantize_per_channel(w: np.ndarray, bits: int = 4, scale_dtype: str = "f16") -> tuple[np.ndarray, np.ndarray]:
+    """Symmetric round-to-nearest quantisation of w (N, K), one scale per output channel n.
+
+    Returns (q int8 (N, K) in [-2^(bits-1), 2^(bits-1)-1], scale bit patterns uint16 (N,)).  The scale is
+    amax / (2^(bits-1) - 1) rounded to the 16-bit type FIRST, and q is computed against the rounded scale, so
+    dequantising with the stored scale reproduces the grid the quantiser used."""
+    if bits not in (4, 8):
+        raise ValueError("bits must be 4 or 8")
+    w = np.asarray(w, np.float32)
+    qmax = 2 ** (bits - 1) - 1
+    amax = np.abs(w).max(axis=1)
+    s_bits = _to_bits(np.where(amax > 0, amax / qmax, 1.0), scale_dtype)
+    s = _from_bits(s_bits, scale_dtype)
+    q = np.clip(np.rint(w / s[:, None]), -qmax - 1, qmax).astype(np.int8)
+    return q, s_bits
+
+
+def pack(q: np.ndarray, scale_bits: np.ndarray, bits: int = 4, scale_dtype: str = "f16") -> PackedWeights:
+    """q int8 (N, K) -> the engine's device format."""
+    q = np.ascontiguousarray(q, np.int8)
+    N, K = q.shape
+    if bits == 4:
+        if K % 8:
+            raise ValueError("K must be a multiple of 8 for packed int4")
+        weight = capi.pack_int4_host(q, K, N)
+    else:
+        weight = q
+    return PackedWeights(weight, np.ascontiguousarray(scale_bits, np.uint16), bits, scale_dtype, N, K)
+
+
+def unpack_int4(packed: np.ndarray, K: int) -> np.ndarray:
+    """Inverse of the packed int4 layout (host side, for inspection and tests): uint8 (N, K//2) -> int8 (N, K).
+    Inside each little-endian 32-bit word nibble p holds k = 8g + 2p (p < 4) or 8g + 2(p - 4) + 1 (p >= 4)."""
+    words = np.ascontiguousarray(packed).view("<u4")            # (N, K//8)
+    N = words.shape[0]
+    out = np.empty((N, K // 8, 8), np.int8)
+    for p in range(8):
+        k = 2 * p if p < 4 else 2 * (p - 4) + 1
+        out[:, :, k] = ((words >> (4 * p)) & 0xF).astype(np.int16) - 8
+    return out.reshape(N, K)
+
+
+def dequantize(pw: PackedWeights) -> np.ndarray:
+    """fp32 (N, K) weights as the kernels see them: q * scale rounded to the scale's 16-bit type."""
+    q = unpack_int4(pw.weight, pw.K) if pw.bits == 4 else pw.weight
+    s = _from_bits(pw.scale, pw.scale_dtype)
+    return _from_bits(_to_bits(q.astype(np.float32) * s[:, None], pw.scale_dtype), pw.scale_dtype)
+
+
+def save_packed(path: str, pw: PackedWeights) -> None:
+    np.savez(path, format=np.array(FORMAT), bits=np.array(pw.bits), scale_dtype=np.array(pw.scale_dtype),
+             N=np.array(pw.N), K=np.array(pw.K), weight=pw.weight, scale=pw.scale)
+
+
+def load_packed(path: str) -> PackedWeights:
+    with np.load(path, allow_pickle=False) as z:
+        if str(z["format"]) != FORMAT:
+            raise ValueError(f"{path}: not a {FORMAT} container")
+        pw = PackedWeights(z["weight"], z["scale"], int(z["bits"]), str(z["scale_dtype"]), int(z["N"]), int(z["K"]))
+    want = (pw.N, pw.K // 2) if pw.bits == 4 else (pw.N, pw.K)
+    if pw.weight.shape != want or pw.scale.shape != (pw.N,):
+        raise ValueError(f"{path}: array shapes do not match N = {pw.N}, K = {pw.K}, bits = {pw.bits}")
+    return pw

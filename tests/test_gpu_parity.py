@@ -623,3 +623,33 @@ def test_tile256_splitk_and_slices(port):
     for kb in (2, 3, 5):
         got = run_fpaintb(a, bp, s, M, N, K, k_batch=kb, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
         np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("bits,dt", [(4, torch.float16), (8, torch.bfloat16)])
+def test_torch_linear_over_packed_weights(tmp_path, bits, dt):
+    """Quantise -> pack -> save -> load -> WqLinear (torch custom op over the C ABI) against a float64 matmul with the
+    dequantised weights; ragged batch (rows padded to whole tiles inside the op) and a bias + FastGelu epilogue."""
+    from composable_kernel_amd import weights
+    from composable_kernel_amd.torch_ops import WqLinear
+    rng = np.random.default_rng(bits)
+    N, K = 384, 512
+    sdt = "f16" if dt == torch.float16 else "bf16"
+    w = rng.normal(0, 0.05, (N, K)).astype(np.float32)
+    q, s = weights.quantize_per_channel(w, bits, sdt)
+    path = str(tmp_path / "layer.npz")
+    weights.save_packed(path, weights.pack(q, s, bits, sdt))
+    pw = weights.load_packed(path)
+    wd = torch.from_numpy(weights.dequantize(pw)).double()
+    x = torch.from_numpy(rng.uniform(-1, 1, (3, 50, K)).astype(np.float32)).to(dt)
+    tol = 2e-3 if dt == torch.float16 else 1.6e-2
+    y = WqLinear(pw)(x.cuda())
+    assert y.shape == (3, 50, N) and y.dtype == dt
+    ref = x.double() @ wd.T
+    assert torch.allclose(y.cpu().double(), ref, rtol=tol, atol=tol)
+    bias = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32))
+    y = WqLinear(pw, bias=bias, epilogue="fastgelu")(x.cuda())
+    z = ref + bias.to(dt).double()
+    gelu = z / (1 + torch.exp(z * (-2 * 0.035677 * z * z - 2 * 0.797885)))
+    assert torch.allclose(y.cpu().double(), gelu, rtol=tol, atol=tol)
+    # registered as a dispatcher operator (usable from torch.compile graphs through its fake implementation)
+    assert torch.ops.wqgemm.fpaintb_linear is not None
