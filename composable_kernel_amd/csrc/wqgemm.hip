@@ -11,6 +11,7 @@
 #define WQ_MAIN_TU
 #include "wqgemm.h"
 #include "wq_kernels.h"
+#include "wq_gemm_skinny.h"
 
 // The 256-tile kernels are compiled one translation unit per (activation, weight format) pair
 // (wq_inst_256.hip) so that the build runs in parallel.
@@ -52,6 +53,7 @@ enum Route
     ROUTE_MFMA256,
     ROUTE_I8_MFMA128,
     ROUTE_F8_MFMA256,
+    ROUTE_SKINNY,
     ROUTE_GENERIC
 };
 
@@ -66,6 +68,7 @@ struct Plan
     int k_per_z   = 0;
     bool partial  = false; // main kernel writes fp32 partial slabs
     bool to_c     = false; // ... directly into p->c (multi-GPU slice) instead of the workspace
+    bool auto_split = false; // small-M kernel: split-K chosen by the planner, needs (and is dropped without) a workspace
     bool via_colb = false; // row-major 8-bit B: transpose into the workspace, then the K-contiguous matrix-core kernels
     bool via_f16  = false; // fp8 FNUZ activations: convert to fp16 in the workspace, then the fp16 MFMA kernel
 };
@@ -190,6 +193,44 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
                        ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
     plan.route = tiled && !(p->flags & WQ_FLAG_GENERIC) ? ROUTE_MFMA128 : ROUTE_GENERIC;
+    // Small M (decode-like shapes): HBM-bound, one pass over the weights; its own kernel with split-K for occupancy.
+    {
+        const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64; // k per super-step of wq_gemm_skinny
+        const int nmb       = (p->M + 15) / 16;
+        const int klen_all  = plan.k_end - plan.k_begin;
+        const int klen_cap  = ((128 * 1024) / (nmb > 0 ? nmb * 16 : 16) - 16) / 2 / ks * ks; // LDS holds the A slice
+        const bool eligible = is16(p->a_dtype) && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
+                              p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 &&
+                              klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
+                              p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 &&
+                              (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0;
+        if(eligible)
+        {
+            int kb = plan.k_batch, per = klen_all;
+            if(kb > 1)
+                per = wqgemm_splitk_kread(klen_all, kb, ks);
+            else if(!slice)
+            {
+                // enough workgroups for two per CU, and A slices that fit LDS
+                const int want = (512 + p->N / 64 - 1) / (p->N / 64);
+                const int need = (klen_all + klen_cap - 1) / klen_cap;
+                kb             = want > need ? want : need;
+                if(kb > klen_all / ks)
+                    kb = klen_all / ks;
+                per = wqgemm_splitk_kread(klen_all, kb, ks);
+                kb  = (klen_all + per - 1) / per; // no empty slices
+            }
+            if(per <= klen_cap)
+            {
+                plan.route      = ROUTE_SKINNY;
+                plan.auto_split = !slice && plan.k_batch == 1 && kb > 1;
+                plan.k_batch    = kb;
+                plan.k_per_z    = per;
+                plan.partial    = slice || kb > 1;
+                return WQ_OK;
+            }
+        }
+    }
     // 8-bit weights stored (K, N) row-major (the B layout of client_example/30_gemm_bf16Aint8B): the matrix-core
     // kernels want K contiguous, so the launch first transposes B into the workspace (HBM-bound, 2 K N bytes);
     // without a workspace the general kernel runs.
@@ -250,6 +291,35 @@ template <int AK, int BKIND>
 void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
 {
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
+}
+
+template <int AK, int BKIND>
+int launch_skinny_t(const wq::GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
+{
+    static bool opted_in[64] = {}; // more than 64 KiB of dynamic LDS must be opted into once per device
+    int dev                  = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return WQ_ERR_HIP;
+    if(dev >= 0 && dev < 64 && !opted_in[dev])
+    {
+        if(hipFuncSetAttribute((const void*)wq::wq_gemm_skinny<AK, BKIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               144 * 1024) != hipSuccess)
+            return WQ_ERR_HIP;
+        opted_in[dev] = true;
+    }
+    hipLaunchKernelGGL((wq::wq_gemm_skinny<AK, BKIND>), grid, dim3(256), lds_bytes, s, gp);
+    return WQ_OK;
+}
+
+int launch_skinny(int ak, int bk, const wq::GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
+{
+    if(ak == wq::A_F16)
+        return bk == wq::B_I4P   ? launch_skinny_t<wq::A_F16, wq::B_I4P>(gp, grid, lds_bytes, s)
+               : bk == wq::B_U8O ? launch_skinny_t<wq::A_F16, wq::B_U8O>(gp, grid, lds_bytes, s)
+                                 : launch_skinny_t<wq::A_F16, wq::B_I8>(gp, grid, lds_bytes, s);
+    return bk == wq::B_I4P   ? launch_skinny_t<wq::A_BF16, wq::B_I4P>(gp, grid, lds_bytes, s)
+           : bk == wq::B_U8O ? launch_skinny_t<wq::A_BF16, wq::B_U8O>(gp, grid, lds_bytes, s)
+                             : launch_skinny_t<wq::A_BF16, wq::B_I8>(gp, grid, lds_bytes, s);
 }
 
 int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipStream_t s)
@@ -363,6 +433,22 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
             else
                 launch_mfma128<wq::A_BF16, wq::B_I8>(gp, grid, s);
         }
+    }
+    else if(plan.route == ROUTE_SKINNY)
+    {
+        wq::GemmParams gp{};
+        gp.a = p->a, gp.b = p->b, gp.scale = p->scale, gp.c = out;
+        gp.M = p->M, gp.N = p->N, gp.K = p->K;
+        gp.lda = p->lda, gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb, gp.ldc = ld_out;
+        gp.k_begin = plan.k_begin, gp.k_end = plan.k_end, gp.k_per_z = plan.k_per_z;
+        gp.partial = plan.partial ? 1 : 0;
+        gp.epi     = epilogue_of(p);
+        const int nmb       = (p->M + 15) / 16;
+        const int lds_bytes = nmb * 16 * (plan.k_per_z * 2 + 16);
+        const dim3 grid(p->N / 64, 1, plan.k_batch);
+        const int rc = launch_skinny(plan.ak, plan.bk, gp, grid, lds_bytes, s);
+        if(rc != WQ_OK)
+            return fail(WQ_ERR_HIP, "small-M kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     else if(plan.route == ROUTE_I8_MFMA128)
     {
@@ -486,6 +572,19 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     if(rc != WQ_OK)
         return rc;
     hipStream_t s = (hipStream_t)stream;
+    if(plan.auto_split && !workspace)
+    {
+        // the planner's own split-K is an optimisation: without a workspace run one slice, or the general kernel
+        // when the activations of the whole K range do not fit LDS
+        const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, nmb = (p->M + 15) / 16;
+        const int klen_cap = ((128 * 1024) / (nmb * 16) - 16) / 2 / ks * ks;
+        plan.auto_split = false;
+        plan.k_batch    = 1;
+        plan.partial    = false;
+        plan.k_per_z    = plan.k_end - plan.k_begin;
+        if(plan.k_per_z > klen_cap)
+            plan.route = ROUTE_GENERIC;
+    }
     if(plan.partial && !plan.to_c && !workspace)
         return fail(WQ_ERR_WORKSPACE, "k_batch = %d needs a workspace of %zu bytes", plan.k_batch,
                     (size_t)plan.k_batch * p->M * p->N * sizeof(float));
@@ -555,6 +654,9 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
                  "DeviceGemmMultiplyMultiply_WeightQuant_Mfma_gfx950<512, 256, 256, 128, 16x16x128_f8f6f4, %s, %s, %s, "
                  "LdsDma, ConvertInRegister, KBatch%d>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
+    else if(plan.route == ROUTE_SKINNY)
+        snprintf(buf, n, "DeviceFpAintBGemm_SmallM_gfx950<256, 64, 64, 16x16x32, %s, %s, %s, StreamB, KBatch%d>",
+                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
     else if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
         snprintf(buf, n,
                  "DeviceFpAintBGemm_Mfma_gfx950<%s, 64, 16x16x32, %s, %s, %s, LdsDma, "
@@ -579,6 +681,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"
+             : plan.route == ROUTE_SKINNY ? "wq_gemm_skinny"
              : plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128"
                                            : "wq_gemm_generic");
     return WQ_OK;

@@ -35,7 +35,7 @@ def bits_to_f32(bits: np.ndarray, dtype: int) -> np.ndarray:
 
 def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b_dtype=capi.I4_PACKED,
                 lda=None, ldb=None, ldc=None, epilogue=capi.EPI_PASSTHROUGH, d0=None, d1=None,
-                k_batch=1, expect_kernel=None, b_layout=capi.COL_MAJOR, flags=0):
+                k_batch=1, expect_kernel=None, b_layout=capi.COL_MAJOR, flags=0, use_workspace=True):
     """Run one fpAintB GEMM through the C ABI; returns the (M, ldc) uint16 output bits."""
     a_t = dev(a_bits)
     b_t = b_dev_bytes if isinstance(b_dev_bytes, torch.Tensor) else dev(b_dev_bytes)
@@ -57,7 +57,7 @@ def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b
         assert capi.kernel_name(p) == expect_kernel, (capi.kernel_name(p), capi.type_string(p))
     ws = None
     nbytes = capi.workspace_bytes(p)
-    if nbytes:
+    if nbytes and use_workspace:
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     capi.launch(p, ws.data_ptr() if ws is not None else None, stream)

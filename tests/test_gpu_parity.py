@@ -126,7 +126,11 @@ def test_bf16_int8_golden_generic_all_epilogues(golden_gemm):
     M, N, K = 48, 64, 128
     for ep, kind in ((0, capi.EPI_PASSTHROUGH), (1, capi.EPI_FASTGELU), (2, capi.EPI_MULTIPLY_ADD_FASTGELU)):
         got = run_fpaintb(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
-                          epilogue=kind, d0=g["bf16_d0"], d1=g["bf16_d1"], expect_kernel=GENERIC)
+                          epilogue=kind, d0=g["bf16_d0"], d1=g["bf16_d1"], flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
+        # (the default route for 48 rows is the small-M kernel: same result up to the summation order)
+        dflt = run_fpaintb(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
+                           epilogue=kind, d0=g["bf16_d0"], d1=g["bf16_d1"], expect_kernel="wq_gemm_skinny")
+        check_err(bits_to_f32(dflt, capi.BF16), bits_to_f32(got, capi.BF16), 1e-2, 1e-3)
         exp = g[f"bf16_e_col_ep{ep}"].reshape(M, N)
         if ep == 0:
             np.testing.assert_array_equal(got, exp)   # same order, truncating store: bit-exact
@@ -167,7 +171,7 @@ def test_bf16_int8_multi_abd_family_golden(golden_gemm):
 
     for ep in (3, 4, 5, 6):
         got = run_fpaintb(a, g["bf16_bcol"], s, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=kinds[ep], d0=d0,
-                          expect_kernel=GENERIC)
+                          flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
         same(got, g[f"bf16_e_col_ep{ep}"], ep in (4, 6))
     brow = np.ascontiguousarray(g["bf16_bcol"].T)
     for ep in (0, 2, 5, 6):
@@ -623,6 +627,54 @@ def test_tile256_splitk_and_slices(port):
     for kb in (2, 3, 5):
         got = run_fpaintb(a, bp, s, M, N, K, k_batch=kb, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
         np.testing.assert_array_equal(got, exp)
+
+
+SKINNY = "wq_gemm_skinny"
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 48, 64])
+@pytest.mark.parametrize("a_dtype,b_dtype", [(capi.F16, capi.I4_PACKED), (capi.F16, capi.U8_OFFSET), (capi.BF16, capi.I8),
+                                             (capi.BF16, capi.I4_PACKED)])
+def test_small_m_kernel(port, M, a_dtype, b_dtype):
+    """Decode-like shapes (M <= 64): the streaming small-M kernel with the planner's split-K (workspace given),
+    as a single slice (no workspace), with a caller's k_batch and with an epilogue; rows beyond M stay untouched."""
+    rng = np.random.default_rng(1000 * M + 10 * a_dtype + b_dtype)
+    N, K = 192, 1024
+    lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
+    q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+    if b_dtype == capi.I4_PACKED:
+        b = pack_on_device(q, K, N)
+    elif b_dtype == capi.U8_OFFSET:
+        b = (q.astype(np.int16) + 128).astype(np.uint8)
+    else:
+        b = q
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+
+    def ref(a, s, ep=0, d0=None, d1=None):
+        if a_dtype == capi.F16:
+            return port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+        return port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, ep, d0, d1).reshape(M, N)
+
+    a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+    s = cvt(rng.integers(1, 3, N).astype(np.float32))
+    exp = ref(a, s)
+    for kw in (dict(), dict(use_workspace=False), dict(k_batch=3)):
+        got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=SKINNY, **kw)
+        np.testing.assert_array_equal(got, exp)
+    a = cvt(rng.uniform(-1, 1, (M, K)))
+    s = cvt(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    tol = 1e-3 if a_dtype == capi.F16 else 1e-2
+    got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=SKINNY)
+    check_err(bits_to_f32(got, a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3)
+    if a_dtype == capi.BF16:
+        d0 = bf16_bits(rng.uniform(-0.5, 0.5, N))
+        got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, epilogue=capi.EPI_ADD_FASTGELU, d0=d0,
+                          expect_kernel=SKINNY)
+        check_err(bits_to_f32(got, a_dtype), bits_to_f32(ref(a, s, 4, d0, d0), a_dtype), tol, 1e-3)
+    # padded output rows (ldc > N) keep their poison
+    got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, ldc=N + 8, expect_kernel=SKINNY)
+    assert (got[:, N:] == 0x7BFF).all()
+    check_err(bits_to_f32(got[:, :N], a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3)
 
 
 @pytest.mark.parametrize("bits,dt", [(4, torch.float16), (8, torch.bfloat16)])
