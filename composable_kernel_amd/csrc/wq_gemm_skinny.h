@@ -20,13 +20,17 @@
 
 namespace wq {
 
-template <int AK, int BKIND>
+// NMB: 16-row blocks of activations computed (1 for M <= 16, else 4; rows beyond M are zero in LDS and never stored).
+// P:   weight loads in flight per lane; the number of super-steps of a K slice must be a multiple of P, which keeps
+//      the loop body free of branches (so the compiler's wait counts leave P - 1 loads in flight and it can hoist
+//      the LDS reads of a super-step over its arithmetic).  The planner picks slices that allow P = 4; P = 1 serves
+//      everything else.
+template <int AK, int BKIND, int NMB, int P>
 __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 {
     constexpr int CH    = BKIND == B_I4P ? 32 : 16; // k per lane per super-step (16 bytes of weights)
     constexpr int KS    = 4 * CH;                   // k per super-step
     constexpr int STEPS = CH / 8;                   // MFMA k-steps per super-step
-    constexpr int P     = 4;                        // weight loads in flight per lane
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
     const int lane = threadIdx.x & 63;
@@ -38,23 +42,24 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
     const int kz_begin = p.k_begin + blockIdx.z * p.k_per_z;
     const int kz_end   = min(p.k_end, kz_begin + p.k_per_z);
     const int klen     = max(0, kz_end - kz_begin);
-    const int nsteps   = klen / KS;
-    const int nmb      = (p.M + 15) >> 4;
+    const int nsteps   = klen / KS; // a multiple of P (host-checked)
 
-    // ---- weight stream: first loads go out before anything else ---------------------------------------------
+    // ---- weight stream: the first P loads go out before anything else --------------------------------------------
     const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
                           (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
     u4_t raw[P];
+    if(nsteps > 0)
+    {
 #pragma unroll
-    for(int i = 0; i < P; ++i)
-        if(i < nsteps)
+        for(int i = 0; i < P; ++i)
             raw[i] = *(const u4_t*)(bptr + (size_t)i * 64);
+    }
 
-    // ---- activations of this K slice -> LDS, rows >= M zero-filled; row pitch klen * 2 + 16 bytes ------------
+    // ---- activations of this K slice -> LDS, rows >= M zero-filled; row pitch klen * 2 + 16 bytes ----------------
     const int pitch = klen * 2 + 16;
     {
         const int chunks_per_row = klen / 8; // 16-byte chunks
-        const int total          = nmb * 16 * chunks_per_row;
+        const int total          = NMB * 16 * chunks_per_row;
         for(int i = threadIdx.x; i < total; i += 256)
         {
             const int row = i / chunks_per_row, ch = i - row * chunks_per_row;
@@ -68,9 +73,9 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
     sc.set(p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>());
     __syncthreads();
 
-    f4_t acc[4];
+    f4_t acc[NMB];
 #pragma unroll
-    for(int mb = 0; mb < 4; ++mb)
+    for(int mb = 0; mb < NMB; ++mb)
         acc[mb] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     const uint8_t* a_lane = lds + fr * pitch + fq * CH * 2;
@@ -79,40 +84,39 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 #pragma unroll
         for(int i = 0; i < P; ++i)
         {
-            if(t + i < nsteps) // wave-uniform
+            const u4_t w = raw[i];
+            // prefetch super-step t + i + P; past the end re-load the last one (valid memory, value unused)
+            const int nxt = min(t + i + P, nsteps - 1);
+            raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * 64);
+            u4_t af[STEPS][NMB];
+#pragma unroll
+            for(int s = 0; s < STEPS; ++s)
+#pragma unroll
+                for(int mb = 0; mb < NMB; ++mb)
+                    af[s][mb] = *(const u4_t*)(a_lane + ((t + i) * KS + 8 * s) * 2 + mb * 16 * pitch);
+#pragma unroll
+            for(int s = 0; s < STEPS; ++s)
             {
-                const u4_t w = raw[i];
-                if(t + i + P < nsteps)
-                    raw[i] = *(const u4_t*)(bptr + (size_t)(t + i + P) * 64);
-#pragma unroll
-                for(int s = 0; s < STEPS; ++s)
+                u4_t wf;
+                if constexpr(BKIND == B_I4P)
+                    wf = dequant8(sc, w[s], std::integral_constant<int, B_I4P>{});
+                else
                 {
-                    u4_t wf;
-                    if constexpr(BKIND == B_I4P)
-                        wf = dequant8(sc, w[s], std::integral_constant<int, B_I4P>{});
+                    const u2_t w8 = {w[2 * s], w[2 * s + 1]};
+                    if constexpr(AK == A_F16)
+                        wf = dequant8_bytes_f16<BKIND>(sc, w8);
                     else
-                    {
-                        const u2_t w8 = {w[2 * s], w[2 * s + 1]};
-                        if constexpr(AK == A_F16)
-                            wf = dequant8_bytes_f16<BKIND>(sc, w8);
-                        else
-                            wf = dequant8_bytes_bf16<BKIND>(sc, w8);
-                    }
-                    const uint8_t* a_step = a_lane + ((t + i) * KS + 8 * s) * 2;
+                        wf = dequant8_bytes_bf16<BKIND>(sc, w8);
+                }
 #pragma unroll
-                    for(int mb = 0; mb < 4; ++mb)
-                    {
-                        if(mb < nmb) // uniform
-                        {
-                            const u4_t af = *(const u4_t*)(a_step + mb * 16 * pitch);
-                            if constexpr(AK == A_F16)
-                                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wf),
-                                                                                 __builtin_bit_cast(h8_t, af), acc[mb], 0, 0, 0);
-                            else
-                                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, wf),
-                                                                                  __builtin_bit_cast(bf8_t, af), acc[mb], 0, 0, 0);
-                        }
-                    }
+                for(int mb = 0; mb < NMB; ++mb)
+                {
+                    if constexpr(AK == A_F16)
+                        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wf),
+                                                                         __builtin_bit_cast(h8_t, af[s][mb]), acc[mb], 0, 0, 0);
+                    else
+                        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, wf),
+                                                                          __builtin_bit_cast(bf8_t, af[s][mb]), acc[mb], 0, 0, 0);
                 }
             }
         }
@@ -120,10 +124,10 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 
     // ---- store: lane holds C[16 mb + fr][n0 + 4 fq .. +3] --------------------------------------------------------
 #pragma unroll
-    for(int mb = 0; mb < 4; ++mb)
+    for(int mb = 0; mb < NMB; ++mb)
     {
         const int m = mb * 16 + fr;
-        if(mb < nmb && m < p.M)
+        if(m < p.M)
         {
             const int n = n0 + fq * 4;
             if(p.partial)
@@ -140,6 +144,121 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
                 *(u2_t*)((uint16_t*)p.c + (size_t)m * p.ldc + n) = pk;
             }
         }
+    }
+}
+
+// Variant for M <= 16 that needs neither split-K workspace nor a reduce kernel: the four waves of a workgroup
+// own the SAME 16 columns and a quarter of K each; their accumulators are summed through LDS and wave 0 applies
+// the epilogue.  grid (N / 16), 256 threads.  Only the M real rows of the activations are staged (lanes of the
+// zero rows read nothing), so M = 1 costs 2 K bytes of LDS.  Super-steps per wave must be a multiple of P.
+template <int AK, int BKIND, int P>
+__global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
+{
+    constexpr int CH    = BKIND == B_I4P ? 32 : 16;
+    constexpr int KS    = 4 * CH;
+    constexpr int STEPS = CH / 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr   = lane & 15;
+    const int fq   = lane >> 4;
+    const int n0   = blockIdx.x * 16;
+
+    const int klen   = p.k_end - p.k_begin;
+    const int kw     = klen / 4;            // K range of one wave
+    const int nsteps = kw / KS;             // a multiple of P (host-checked), >= P
+    const int kbeg   = p.k_begin + wave * kw;
+
+    const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
+                          (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
+    u4_t raw[P];
+#pragma unroll
+    for(int i = 0; i < P; ++i)
+        raw[i] = *(const u4_t*)(bptr + (size_t)i * 64);
+
+    // activations: rows 0 .. M-1 of [k_begin, k_end), row pitch klen * 2 + 16 bytes
+    const int pitch = klen * 2 + 16;
+    {
+        const int chunks_per_row = klen / 8;
+        const int total          = p.M * chunks_per_row;
+        for(int i = threadIdx.x; i < total; i += 256)
+        {
+            const int row = i / chunks_per_row, ch = i - row * chunks_per_row;
+            *(u4_t*)(lds + row * pitch + ch * 16) =
+                *(const u4_t*)((const uint8_t*)p.a + ((size_t)row * p.lda + p.k_begin) * 2 + ch * 16);
+        }
+    }
+    ScaleReg<AK> sc;
+    sc.set(p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>());
+    __syncthreads();
+
+    f4_t acc            = {0.f, 0.f, 0.f, 0.f};
+    const bool live     = fr < p.M; // this lane's activation row exists
+    const uint8_t* a_ln = lds + (live ? fr : 0) * pitch + (wave * kw + fq * CH) * 2;
+    for(int t = 0; t < nsteps; t += P)
+    {
+#pragma unroll
+        for(int i = 0; i < P; ++i)
+        {
+            const u4_t w  = raw[i];
+            const int nxt = min(t + i + P, nsteps - 1);
+            raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * 64);
+            u4_t af[STEPS];
+#pragma unroll
+            for(int s = 0; s < STEPS; ++s)
+            {
+                af[s] = *(const u4_t*)(a_ln + ((t + i) * KS + 8 * s) * 2);
+                if(!live)
+                    af[s] = u4_t{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for(int s = 0; s < STEPS; ++s)
+            {
+                u4_t wf;
+                if constexpr(BKIND == B_I4P)
+                    wf = dequant8(sc, w[s], std::integral_constant<int, B_I4P>{});
+                else
+                {
+                    const u2_t w8 = {w[2 * s], w[2 * s + 1]};
+                    if constexpr(AK == A_F16)
+                        wf = dequant8_bytes_f16<BKIND>(sc, w8);
+                    else
+                        wf = dequant8_bytes_bf16<BKIND>(sc, w8);
+                }
+                if constexpr(AK == A_F16)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wf), __builtin_bit_cast(h8_t, af[s]),
+                                                                 acc, 0, 0, 0);
+                else
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, wf),
+                                                                  __builtin_bit_cast(bf8_t, af[s]), acc, 0, 0, 0);
+            }
+        }
+    }
+
+    // sum the four K quarters in ascending order through LDS (the activation image is no longer needed)
+    __syncthreads();
+    f4_t* red = (f4_t*)lds;
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if(wave == 0 && live)
+    {
+        f4_t v = red[lane];
+#pragma unroll
+        for(int w = 1; w < 4; ++w)
+        {
+            const f4_t u = red[w * 64 + lane];
+            v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+        }
+        const int m = fr, n = n0 + fq * 4;
+        uint16_t o[4];
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+            o[j] = cvt_out16(apply_epilogue(p.epi, v[j], m, n + j), p.epi.c_dtype);
+        u2_t pk;
+        pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *(u2_t*)((uint16_t*)p.c + (size_t)m * p.ldc + n) = pk;
     }
 }
 

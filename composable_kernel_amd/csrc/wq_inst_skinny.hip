@@ -1,0 +1,89 @@
+// Translation unit of the small-M kernel family.
+#include <hip/hip_runtime.h>
+
+#include "wqgemm.h"
+#include "wq_gemm_skinny.h"
+
+namespace wq {
+
+namespace {
+
+template <int AK, int BKIND, int NMB, int P>
+int launch_t(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
+{
+    static bool opted_in[64] = {}; // more than 64 KiB of dynamic LDS must be opted into once per device
+    int dev                  = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return WQ_ERR_HIP;
+    if(dev >= 0 && dev < 64 && !opted_in[dev])
+    {
+        if(hipFuncSetAttribute((const void*)wq_gemm_skinny<AK, BKIND, NMB, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               144 * 1024) != hipSuccess)
+            return WQ_ERR_HIP;
+        opted_in[dev] = true;
+    }
+    hipLaunchKernelGGL((wq_gemm_skinny<AK, BKIND, NMB, P>), grid, dim3(256), lds_bytes, s, gp);
+    return WQ_OK;
+}
+
+template <int AK, int BKIND>
+int launch_ab(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int nmb, int p)
+{
+    if(nmb == 1)
+        return p == 4 ? launch_t<AK, BKIND, 1, 4>(gp, grid, lds_bytes, s) : launch_t<AK, BKIND, 1, 1>(gp, grid, lds_bytes, s);
+    return p == 4 ? launch_t<AK, BKIND, 4, 4>(gp, grid, lds_bytes, s) : launch_t<AK, BKIND, 4, 1>(gp, grid, lds_bytes, s);
+}
+
+template <int AK, int BKIND, int P>
+int launch_ws_t(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
+{
+    static bool opted_in[64] = {};
+    int dev                  = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return WQ_ERR_HIP;
+    if(dev >= 0 && dev < 64 && !opted_in[dev])
+    {
+        if(hipFuncSetAttribute((const void*)wq_gemm_skinny_ws<AK, BKIND, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               144 * 1024) != hipSuccess)
+            return WQ_ERR_HIP;
+        opted_in[dev] = true;
+    }
+    hipLaunchKernelGGL((wq_gemm_skinny_ws<AK, BKIND, P>), grid, dim3(256), lds_bytes, s, gp);
+    return WQ_OK;
+}
+
+template <int AK, int BKIND>
+int launch_ws_ab(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int p)
+{
+    return p == 4   ? launch_ws_t<AK, BKIND, 4>(gp, grid, lds_bytes, s)
+           : p == 2 ? launch_ws_t<AK, BKIND, 2>(gp, grid, lds_bytes, s)
+                    : launch_ws_t<AK, BKIND, 1>(gp, grid, lds_bytes, s);
+}
+
+} // namespace
+
+// waves-split-K variant (M <= 16): p = loads in flight, super-steps per wave % p == 0
+int launch_skinny_ws(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int p)
+{
+    if(ak == A_F16)
+        return bk == B_I4P   ? launch_ws_ab<A_F16, B_I4P>(gp, grid, lds_bytes, s, p)
+               : bk == B_U8O ? launch_ws_ab<A_F16, B_U8O>(gp, grid, lds_bytes, s, p)
+                             : launch_ws_ab<A_F16, B_I8>(gp, grid, lds_bytes, s, p);
+    return bk == B_I4P   ? launch_ws_ab<A_BF16, B_I4P>(gp, grid, lds_bytes, s, p)
+           : bk == B_U8O ? launch_ws_ab<A_BF16, B_U8O>(gp, grid, lds_bytes, s, p)
+                         : launch_ws_ab<A_BF16, B_I8>(gp, grid, lds_bytes, s, p);
+}
+
+// nmb: 1 or 4 sixteen-row blocks staged and computed; p: 4 or 1 loads in flight (super-steps per slice % p == 0)
+int launch_skinny(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int nmb, int p)
+{
+    if(ak == A_F16)
+        return bk == B_I4P   ? launch_ab<A_F16, B_I4P>(gp, grid, lds_bytes, s, nmb, p)
+               : bk == B_U8O ? launch_ab<A_F16, B_U8O>(gp, grid, lds_bytes, s, nmb, p)
+                             : launch_ab<A_F16, B_I8>(gp, grid, lds_bytes, s, nmb, p);
+    return bk == B_I4P   ? launch_ab<A_BF16, B_I4P>(gp, grid, lds_bytes, s, nmb, p)
+           : bk == B_U8O ? launch_ab<A_BF16, B_U8O>(gp, grid, lds_bytes, s, nmb, p)
+                         : launch_ab<A_BF16, B_I8>(gp, grid, lds_bytes, s, nmb, p);
+}
+
+} // namespace wq

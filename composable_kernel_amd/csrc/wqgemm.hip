@@ -11,7 +11,6 @@
 #define WQ_MAIN_TU
 #include "wqgemm.h"
 #include "wq_kernels.h"
-#include "wq_gemm_skinny.h"
 
 // The 256-tile kernels are compiled one translation unit per (activation, weight format) pair
 // (wq_inst_256.hip) so that the build runs in parallel.
@@ -21,6 +20,8 @@ WQ_DECL_256(0, 0) WQ_DECL_256(0, 1) WQ_DECL_256(0, 2) WQ_DECL_256(1, 0) WQ_DECL_
 #undef WQ_DECL_256
 int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant); // wq_inst_256_f8.hip
 int launch_256_w32(const GemmParams& gp, dim3 grid, hipStream_t s, int ak);    // wq_inst_256_w32.hip
+int launch_skinny(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int nmb, int p); // wq_inst_skinny.hip
+int launch_skinny_ws(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int p);
 } // namespace wq
 
 namespace {
@@ -54,6 +55,7 @@ enum Route
     ROUTE_I8_MFMA128,
     ROUTE_F8_MFMA256,
     ROUTE_SKINNY,
+    ROUTE_SKINNY_WS,
     ROUTE_GENERIC
 };
 
@@ -196,7 +198,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // Small M (decode-like shapes): HBM-bound, one pass over the weights; its own kernel with split-K for occupancy.
     {
         const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64; // k per super-step of wq_gemm_skinny
-        const int nmb       = (p->M + 15) / 16;
+        const int nmb       = p->M <= 16 ? 1 : 4; // 16-row blocks staged in LDS
         const int klen_all  = plan.k_end - plan.k_begin;
         const int klen_cap  = ((128 * 1024) / (nmb > 0 ? nmb * 16 : 16) - 16) / 2 / ks * ks; // LDS holds the A slice
         const bool eligible = is16(p->a_dtype) && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
@@ -204,6 +206,14 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                               klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
                               p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 &&
                               (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0;
+        // M <= 16 with the whole K range of the real rows in LDS: four waves split K inside the workgroup, one
+        // kernel, no workspace
+        if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all % (4 * ks) == 0 && p->N % 16 == 0 &&
+           (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024 && p->N / 16 >= 128) // (larger images cost more than the reduce kernel saves)
+        {
+            plan.route = ROUTE_SKINNY_WS;
+            return WQ_OK;
+        }
         if(eligible)
         {
             int kb = plan.k_batch, per = klen_all;
@@ -217,7 +227,11 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                 kb             = want > need ? want : need;
                 if(kb > klen_all / ks)
                     kb = klen_all / ks;
-                per = wqgemm_splitk_kread(klen_all, kb, ks);
+                // slices of whole 4-super-step groups when K allows (the kernel then keeps 4 loads in flight)
+                const int gran = klen_all % (4 * ks) == 0 ? 4 * ks : ks;
+                if(kb > klen_all / gran)
+                    kb = klen_all / gran;
+                per = wqgemm_splitk_kread(klen_all, kb, gran);
                 kb  = (klen_all + per - 1) / per; // no empty slices
             }
             if(per <= klen_cap)
@@ -291,35 +305,6 @@ template <int AK, int BKIND>
 void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
 {
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
-}
-
-template <int AK, int BKIND>
-int launch_skinny_t(const wq::GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
-{
-    static bool opted_in[64] = {}; // more than 64 KiB of dynamic LDS must be opted into once per device
-    int dev                  = 0;
-    if(hipGetDevice(&dev) != hipSuccess)
-        return WQ_ERR_HIP;
-    if(dev >= 0 && dev < 64 && !opted_in[dev])
-    {
-        if(hipFuncSetAttribute((const void*)wq::wq_gemm_skinny<AK, BKIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               144 * 1024) != hipSuccess)
-            return WQ_ERR_HIP;
-        opted_in[dev] = true;
-    }
-    hipLaunchKernelGGL((wq::wq_gemm_skinny<AK, BKIND>), grid, dim3(256), lds_bytes, s, gp);
-    return WQ_OK;
-}
-
-int launch_skinny(int ak, int bk, const wq::GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
-{
-    if(ak == wq::A_F16)
-        return bk == wq::B_I4P   ? launch_skinny_t<wq::A_F16, wq::B_I4P>(gp, grid, lds_bytes, s)
-               : bk == wq::B_U8O ? launch_skinny_t<wq::A_F16, wq::B_U8O>(gp, grid, lds_bytes, s)
-                                 : launch_skinny_t<wq::A_F16, wq::B_I8>(gp, grid, lds_bytes, s);
-    return bk == wq::B_I4P   ? launch_skinny_t<wq::A_BF16, wq::B_I4P>(gp, grid, lds_bytes, s)
-           : bk == wq::B_U8O ? launch_skinny_t<wq::A_BF16, wq::B_U8O>(gp, grid, lds_bytes, s)
-                             : launch_skinny_t<wq::A_BF16, wq::B_I8>(gp, grid, lds_bytes, s);
 }
 
 int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipStream_t s)
@@ -443,10 +428,32 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end, gp.k_per_z = plan.k_per_z;
         gp.partial = plan.partial ? 1 : 0;
         gp.epi     = epilogue_of(p);
-        const int nmb       = (p->M + 15) / 16;
+        const int nmb       = p->M <= 16 ? 1 : 4;
+        const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64;
         const int lds_bytes = nmb * 16 * (plan.k_per_z * 2 + 16);
+        // 4 loads in flight when every slice is a whole number of 4-super-step groups
+        const int klen      = plan.k_end - plan.k_begin;
+        const bool by4      = plan.k_per_z % (4 * ks) == 0 && klen % (4 * ks) == 0;
         const dim3 grid(p->N / 64, 1, plan.k_batch);
-        const int rc = launch_skinny(plan.ak, plan.bk, gp, grid, lds_bytes, s);
+        const int rc = wq::launch_skinny(plan.ak, plan.bk, gp, grid, lds_bytes, s, nmb, by4 ? 4 : 1);
+        if(rc != WQ_OK)
+            return fail(WQ_ERR_HIP, "small-M kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    else if(plan.route == ROUTE_SKINNY_WS)
+    {
+        wq::GemmParams gp{};
+        gp.a = p->a, gp.b = p->b, gp.scale = p->scale, gp.c = p->c;
+        gp.M = p->M, gp.N = p->N, gp.K = p->K;
+        gp.lda = p->lda, gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb, gp.ldc = p->ldc;
+        gp.k_begin = plan.k_begin, gp.k_end = plan.k_end;
+        gp.epi     = epilogue_of(p);
+        const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, klen = plan.k_end - plan.k_begin;
+        const int steps_per_wave = klen / 4 / ks;
+        int lds_bytes            = p->M * (klen * 2 + 16);
+        if(lds_bytes < 4096)
+            lds_bytes = 4096; // the cross-wave sum needs 4 x 64 x 16 bytes
+        const int rc = wq::launch_skinny_ws(plan.ak, plan.bk, gp, dim3(p->N / 16), lds_bytes, s,
+                                            steps_per_wave % 4 == 0 ? 4 : (steps_per_wave % 2 == 0 ? 2 : 1));
         if(rc != WQ_OK)
             return fail(WQ_ERR_HIP, "small-M kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
@@ -576,7 +583,7 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     {
         // the planner's own split-K is an optimisation: without a workspace run one slice, or the general kernel
         // when the activations of the whole K range do not fit LDS
-        const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, nmb = (p->M + 15) / 16;
+        const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, nmb = p->M <= 16 ? 1 : 4;
         const int klen_cap = ((128 * 1024) / (nmb * 16) - 16) / 2 / ks * ks;
         plan.auto_split = false;
         plan.k_batch    = 1;
@@ -654,6 +661,9 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
                  "DeviceGemmMultiplyMultiply_WeightQuant_Mfma_gfx950<512, 256, 256, 128, 16x16x128_f8f6f4, %s, %s, %s, "
                  "LdsDma, ConvertInRegister, KBatch%d>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
+    else if(plan.route == ROUTE_SKINNY_WS)
+        snprintf(buf, n, "DeviceFpAintBGemm_SmallM_gfx950<256, 16, 16, 16x16x32, %s, %s, %s, StreamB, WavesSplitK>",
+                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype));
     else if(plan.route == ROUTE_SKINNY)
         snprintf(buf, n, "DeviceFpAintBGemm_SmallM_gfx950<256, 64, 64, 16x16x32, %s, %s, %s, StreamB, KBatch%d>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
@@ -682,6 +692,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"
              : plan.route == ROUTE_SKINNY ? "wq_gemm_skinny"
+             : plan.route == ROUTE_SKINNY_WS ? "wq_gemm_skinny_ws"
              : plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128"
                                            : "wq_gemm_generic");
     return WQ_OK;

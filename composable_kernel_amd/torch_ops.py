@@ -34,8 +34,9 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     M, K = x.shape
     N = scale.shape[0]
     x = x.contiguous()
-    # the matrix-core kernels take whole 128-row tiles: pad the rows of a ragged batch
-    Mp = (M + 127) // 128 * 128 if (N % 128 == 0 and K % 64 == 0) else M
+    # up to 64 rows go to the small-M kernel as they are; beyond that the matrix-core kernels take whole 128-row
+    # tiles, so the rows of a ragged batch are padded
+    Mp = (M + 127) // 128 * 128 if (M > 64 and N % 128 == 0 and K % 64 == 0) else M
     if Mp != M:
         xp = torch.zeros((Mp, K), dtype=x.dtype, device=x.device)
         xp[:M] = x
@@ -44,8 +45,10 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     p = capi.fpAintB_problem(x.data_ptr(), weight.data_ptr(), scale.data_ptr(), y.data_ptr(), Mp, N, K,
                              a_dtype=_DT[x.dtype], b_dtype=capi.I4_PACKED if bits == 4 else capi.I8,
                              epilogue=_EPILOGUES[epilogue], d0=bias.data_ptr() if bias is not None else None)
+    nbytes = capi.workspace_bytes(p)  # optional scratch (the small-M kernel's split-K partials)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
-        capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+        capi.launch(p, ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
     return y[:M] if Mp != M else y
 
 

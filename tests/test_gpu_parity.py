@@ -677,6 +677,47 @@ def test_small_m_kernel(port, M, a_dtype, b_dtype):
     check_err(bits_to_f32(got[:, :N], a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3)
 
 
+@pytest.mark.parametrize("M", [1, 3, 16])
+@pytest.mark.parametrize("a_dtype,b_dtype,K", [(capi.F16, capi.I4_PACKED, 1024), (capi.F16, capi.I4_PACKED, 1536),
+                                               (capi.BF16, capi.I8, 1024), (capi.BF16, capi.I4_PACKED, 512),
+                                               (capi.F16, capi.U8_OFFSET, 768)])
+def test_small_m_kernel_waves_split_k(port, M, a_dtype, b_dtype, K):
+    """M <= 16 with a wide N: one kernel, the four waves of a workgroup split K and sum through LDS (4, 2 or 1 loads
+    in flight depending on the super-steps per wave)."""
+    rng = np.random.default_rng(7 * M + K + b_dtype)
+    N = 2048
+    lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
+    q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+    if b_dtype == capi.I4_PACKED:
+        b = pack_on_device(q, K, N)
+    elif b_dtype == capi.U8_OFFSET:
+        b = (q.astype(np.int16) + 128).astype(np.uint8)
+    else:
+        b = q
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+
+    def ref(a, s):
+        if a_dtype == capi.F16:
+            return port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+        return port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+
+    # (the activation image must stay below 40 KiB of LDS for this variant)
+    name = "wq_gemm_skinny_ws" if M * (2 * K + 16) <= 40 * 1024 else SKINNY
+    a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+    s = cvt(rng.integers(1, 3, N).astype(np.float32))
+    got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=name)
+    np.testing.assert_array_equal(got, ref(a, s))
+    a = cvt(rng.uniform(-1, 1, (M, K)))
+    s = cvt(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    tol = 1e-3 if a_dtype == capi.F16 else 1e-2
+    got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, epilogue=capi.EPI_FASTGELU, ldc=N + 8,
+                      expect_kernel=name)
+    assert (got[:, N:] == 0x7BFF).all()
+    gen = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, epilogue=capi.EPI_FASTGELU, flags=capi.FLAG_GENERIC,
+                      expect_kernel=GENERIC)
+    check_err(bits_to_f32(got[:, :N], a_dtype), bits_to_f32(gen, a_dtype), tol, 1e-3)
+
+
 @pytest.mark.parametrize("bits,dt", [(4, torch.float16), (8, torch.bfloat16)])
 def test_torch_linear_over_packed_weights(tmp_path, bits, dt):
     """Quantise -> pack -> save -> load -> WqLinear (torch custom op over the C ABI) against a float64 matmul with the
@@ -703,5 +744,9 @@ def test_torch_linear_over_packed_weights(tmp_path, bits, dt):
     z = ref + bias.to(dt).double()
     gelu = z / (1 + torch.exp(z * (-2 * 0.035677 * z * z - 2 * 0.797885)))
     assert torch.allclose(y.cpu().double(), gelu, rtol=tol, atol=tol)
+    # a decode-sized batch takes the small-M kernel
+    xs = x[0, :7].contiguous().cuda()
+    ys = WqLinear(pw)(xs)
+    assert torch.allclose(ys.cpu().double(), xs.cpu().double() @ wd.T, rtol=tol, atol=tol)
     # registered as a dispatcher operator (usable from torch.compile graphs through its fake implementation)
     assert torch.ops.wqgemm.fpaintb_linear is not None
