@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A short fixed loop of the fp8 x int4 GEMM (4096^3, MultiplyMultiply + FastGelu) for profiler runs."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from composable_kernel_amd import capi  # noqa: E402
+
+M = N = K = 4096
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev)
+g.manual_seed(5)
+a = (torch.randint(24, 88, (M, K), generator=g, device=dev, dtype=torch.int16) +
+     128 * torch.randint(0, 2, (M, K), generator=g, device=dev, dtype=torch.int16)).to(torch.uint8)
+q = torch.randint(-8, 8, (N, K), generator=g, device=dev, dtype=torch.int8)
+b = torch.empty((N, K // 2), dtype=torch.uint8, device=dev)
+sp = torch.cuda.current_stream().cuda_stream
+capi.pack_int4(q.data_ptr(), K, K, N, b.data_ptr(), K // 2, sp)
+d0 = torch.rand((N,), generator=g, device=dev)
+d1 = torch.rand((M,), generator=g, device=dev)
+c = torch.empty((M, N), dtype=torch.float16, device=dev)
+p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16,
+                         epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU, d0=d0.data_ptr(), d1=d1.data_ptr())
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+for _ in range(n):
+    capi.launch(p, None, sp)
+torch.cuda.synchronize()
+print(capi.kernel_name(p), n, "launches")
