@@ -327,12 +327,18 @@ __device__ __forceinline__ void store_c4(const EpilogueArgs& e, void* c, int ldc
     *(u2_t*)((uint16_t*)c + (size_t)m * ldc + n) = pk;
 }
 
-// quantization_operation.hpp:39-45 on an int32 accumulator
-__device__ __forceinline__ int8_t act_mul_clamp(float requant, int acc)
+// The requantisation family on an int32 accumulator: kind 5 Activation_Mul_Clamp<PassThrough>, 10 <Relu>,
+// 11 / 12 Add_Activation_Mul_Clamp<PassThrough / Relu> with an int32 bias per column
+// (quantization_operation.hpp:39-45,149-156: the bias is added in int32, then float, activation, scale, clamp)
+__device__ __forceinline__ int8_t requant_epilogue(int kind, float requant, int acc, const int32_t* bias, int n)
 {
-    float y = requant * (float)acc;
-    y       = fminf(fmaxf(y, -128.f), 127.f);
-    return (int8_t)y; // toward zero
+    if(kind >= 11)
+        acc += bias[n];
+    float y = (float)acc;
+    if(kind == 10 || kind == 12)
+        y = y > 0.f ? y : 0.f;
+    y = fminf(fmaxf(requant * y, -128.f), 127.f);
+    return (int8_t)y;
 }
 
 __device__ __forceinline__ uint16_t cvt_out16(float v, int c_dtype)

@@ -389,6 +389,8 @@ struct I8GemmParams
     int M, N, K, lda, ldb, ldc;
     int tiles_m, tiles_n, group_m;
     float requant;
+    int kind;            // wq_epilogue of the requantisation family (5, 10, 11, 12)
+    const int32_t* bias; // N values for kinds 11 and 12
 };
 
 __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
             uint32_t pk = 0;
 #pragma unroll
             for(int j = 0; j < 4; ++j)
-                pk |= (uint32_t)(uint8_t)act_mul_clamp(p.requant, acc[nt][mt][j]) << (8 * j);
+                pk |= (uint32_t)(uint8_t)requant_epilogue(p.kind, p.requant, acc[nt][mt][j], p.bias, n + j) << (8 * j);
             *(uint32_t*)((int8_t*)p.c + (size_t)m * p.ldc + n) = pk;
         }
 }
@@ -592,12 +594,13 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
 
     if(p.a_dtype == 4 /*WQ_I8*/)
     {
-        // int8 x int8 -> int32 (exact), then Activation_Mul_Clamp
+        // int8 x int8 -> int32 (exact), then the requantisation functor
         int acc = 0;
         for(int k = kb; k < ke; ++k)
             acc += (int)((const int8_t*)p.a)[m * p.a_sm + k * p.a_sk] *
                    (int)((const int8_t*)p.b)[k * p.b_sk + n * p.b_sn];
-        ((int8_t*)p.c)[(size_t)m * p.ldc + n] = act_mul_clamp(p.epi.requant, acc);
+        ((int8_t*)p.c)[(size_t)m * p.ldc + n] =
+            requant_epilogue(p.epi.kind, p.epi.requant, acc, (const int32_t*)p.epi.d0, n);
         return;
     }
 

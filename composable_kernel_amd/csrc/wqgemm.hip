@@ -127,8 +127,12 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // ---- int8 x int8 requantised GEMM (example/14, client_example/09) ------------------------
     if(p->a_dtype == WQ_I8)
     {
-        if(p->b_dtype != WQ_I8 || p->c_dtype != WQ_I8 || p->epilogue != WQ_EPI_ACT_MUL_CLAMP)
-            return fail(WQ_ERR_UNSUPPORTED, "int8 A needs int8 B, int8 C and Activation_Mul_Clamp");
+        const bool requant_epi = p->epilogue == WQ_EPI_ACT_MUL_CLAMP || p->epilogue == WQ_EPI_RELU_MUL_CLAMP ||
+                                 p->epilogue == WQ_EPI_ADD_ACT_MUL_CLAMP || p->epilogue == WQ_EPI_ADD_RELU_MUL_CLAMP;
+        if(p->b_dtype != WQ_I8 || p->c_dtype != WQ_I8 || !requant_epi)
+            return fail(WQ_ERR_UNSUPPORTED, "int8 A needs int8 B, int8 C and an (Add_)Activation_Mul_Clamp epilogue");
+        if((p->epilogue == WQ_EPI_ADD_ACT_MUL_CLAMP || p->epilogue == WQ_EPI_ADD_RELU_MUL_CLAMP) && !p->d0)
+            return fail(WQ_ERR_INVALID, "epilogue %d needs the int32 bias d0", p->epilogue);
         if(plan.partial)
             return fail(WQ_ERR_UNSUPPORTED, "split-K is not implemented for the int8 requant GEMM");
         const bool tiled_i8 = p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->M % 128 == 0 &&
@@ -466,6 +470,8 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.tiles_m = p->M / 128, gp.tiles_n = p->N / 128;
         gp.group_m = gp.tiles_m >= 8 ? 8 : gp.tiles_m;
         gp.requant = p->requant_scale;
+        gp.kind    = p->epilogue;
+        gp.bias    = (const int32_t*)p->d0;
         hipLaunchKernelGGL(wq::wq_gemm_i8_mfma_128, dim3(gp.tiles_m * gp.tiles_n), dim3(256), 0, s, gp);
     }
     else

@@ -318,7 +318,9 @@ struct DeviceGemmQuantization_gfx950
         p.M = M, p.N = N, p.K = K;
         p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideE;
         p.a = p_a, p.b = p_b, p.c = p_e;
-        p.epilogue      = WQ_EPI_ACT_MUL_CLAMP;
+        p.epilogue      = std::is_same_v<CDEElementwiseOperation, element_wise::Activation_Mul_Clamp<element_wise::Relu>>
+                              ? WQ_EPI_RELU_MUL_CLAMP
+                              : WQ_EPI_ACT_MUL_CLAMP;
         p.requant_scale = cde_op.requantScale_;
         p.k_batch       = 1;
         return arg;
@@ -341,6 +343,70 @@ struct DeviceGemmQuantization_gfx950
     }
     std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
     std::string GetTypeString() const override { return "DeviceGemmQuantization_gfx950<I8, I8, I8, Activation_Mul_Clamp>"; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// E[M,N] = Add_Activation_Mul_Clamp( A[M,K] int8 * B[K,N] int8, bias[N] int32 )   int8 GEMM + bias + requantisation
+// The call shape of example/14_gemm_quantization/gemm_xdl_bias_relu_quantization_int8.cpp:51-94,172-187: one D
+// tensor, the int32 bias, row-major with stride 0 (one value per column).  Activation is PassThrough or Relu.
+// ---------------------------------------------------------------------------------------------
+template <typename ALayout, typename BLayout, typename ELayout, typename Activation>
+struct DeviceGemmBiasQuantization_gfx950
+    : public DeviceGemmMultipleD<ALayout, BLayout, ck::Tuple<tensor_layout::gemm::RowMajor>, ELayout, int8_t, int8_t,
+                                 ck::Tuple<int32_t>, int8_t, element_wise::PassThrough, element_wise::PassThrough,
+                                 element_wise::Add_Activation_Mul_Clamp<Activation>>
+{
+    static_assert(std::is_same_v<Activation, element_wise::PassThrough> || std::is_same_v<Activation, element_wise::Relu>,
+                  "Activation must be PassThrough or Relu");
+    using Argument                = wq_detail::Argument;
+    using Invoker                 = wq_detail::Invoker;
+    using PassThrough             = element_wise::PassThrough;
+    using CDEElementwiseOperation = element_wise::Add_Activation_Mul_Clamp<Activation>;
+
+    static Argument MakeArgument(const void* p_a, const void* p_b, std::array<const void*, 1> p_ds, void* p_e,
+                                 index_t M, index_t N, index_t K, index_t StrideA, index_t StrideB,
+                                 std::array<index_t, 1> StrideDs, index_t StrideE, PassThrough, PassThrough,
+                                 CDEElementwiseOperation cde_op)
+    {
+        Argument arg;
+        wqgemm_problem& p = arg.prob;
+        p.a_dtype = p.b_dtype = p.c_dtype = WQ_I8;
+        p.scale_dtype                     = WQ_F32;
+        p.a_layout                        = wq_detail::layout_of<ALayout>();
+        p.b_layout                        = wq_detail::layout_of<BLayout>();
+        p.c_layout                        = wq_detail::layout_of<ELayout>();
+        p.M = M, p.N = N, p.K = K;
+        p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideE;
+        p.a = p_a, p.b = p_b, p.c = p_e;
+        p.d0            = p_ds[0];
+        p.epilogue      = std::is_same_v<Activation, element_wise::Relu> ? WQ_EPI_ADD_RELU_MUL_CLAMP : WQ_EPI_ADD_ACT_MUL_CLAMP;
+        p.requant_scale = cde_op.requantScale_;
+        p.k_batch       = 1;
+        if(StrideDs[0] != 0) // a full (M, N) bias matrix is not a per-column bias: refused by IsSupportedArgument
+            p.epilogue = -1;
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmBiasQuantization_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument> MakeArgumentPointer(const void* p_a, const void* p_b,
+                                                      std::array<const void*, 1> p_ds, void* p_e, index_t M,
+                                                      index_t N, index_t K, index_t StrideA, index_t StrideB,
+                                                      std::array<index_t, 1> StrideDs, index_t StrideE,
+                                                      PassThrough a_op, PassThrough b_op,
+                                                      CDEElementwiseOperation cde_op) override
+    {
+        return std::make_unique<Argument>(
+            MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE, a_op, b_op, cde_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    std::string GetTypeString() const override
+    {
+        return "DeviceGemmBiasQuantization_gfx950<I8, I8, I32, I8, Add_Activation_Mul_Clamp>";
+    }
 };
 
 // ---------------------------------------------------------------------------------------------

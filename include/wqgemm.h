@@ -60,7 +60,13 @@ typedef enum wq_epilogue
     WQ_EPI_ADD                        = 6, /* binary_element_wise_operation.hpp:78-85: c + d0[n]; d0 of C's type */
     WQ_EPI_ADD_FASTGELU               = 7, /* binary_element_wise_operation.hpp:511-522: FastGelu(c + d0[n])     */
     WQ_EPI_MULTIPLY                   = 8, /* binary_element_wise_operation.hpp Multiply<C>(float, C): c * d0[n] */
-    WQ_EPI_MULTIPLY_FASTGELU          = 9  /* binary_element_wise_operation.hpp:578-590: FastGelu(c * d0[n])     */
+    WQ_EPI_MULTIPLY_FASTGELU          = 9, /* binary_element_wise_operation.hpp:578-590: FastGelu(c * d0[n])     */
+    /* int8 requantisation with Activation = Relu and/or an int32 per-column bias d0[n]
+     * (quantization_operation.hpp:24-66,131-171; unary_element_wise_operation.hpp:409-428;
+     *  example/14_gemm_quantization/gemm_xdl_bias_relu_quantization_int8.cpp:30-32,223-229) */
+    WQ_EPI_RELU_MUL_CLAMP             = 10, /* Activation_Mul_Clamp<Relu>                                  */
+    WQ_EPI_ADD_ACT_MUL_CLAMP          = 11, /* Add_Activation_Mul_Clamp<PassThrough>: int32 d0[n]          */
+    WQ_EPI_ADD_RELU_MUL_CLAMP         = 12  /* Add_Activation_Mul_Clamp<Relu>: int32 d0[n]                 */
 } wq_epilogue;
 
 /* wqgemm_problem.flags */
@@ -118,10 +124,18 @@ const char* wqgemm_last_error(void);
  *  impl/device_fpAintB_gemm_wmma.hpp:510-597). */
 int wqgemm_is_supported(const wqgemm_problem* p);
 
-/* Bytes of device workspace wqgemm_launch can use: k_batch*M*N*4 when k_batch > 1 (required);
- * (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
- * fp16 image of A for the fp16 matrix-core kernel; without it the launch uses the general kernel, which is
- * just as exact and far slower); else 0.
+/* Bytes of device workspace wqgemm_launch can use:
+ *  - k_batch*M*N*4 when the caller sets k_batch > 1 (required: the launch fails with WQ_ERR_WORKSPACE
+ *    without it);
+ *  - kb*M*N*4 when the planner itself splits K for a small-M problem (kb chosen so the grid fills the chip;
+ *    optional: without it the launch runs one K slice, or the general kernel when the activations of the
+ *    whole K range do not fit LDS);
+ *  - (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
+ *    fp16 image of A for the fp16 matrix-core kernel);
+ *  - K*N for tile-aligned row-major (K x N) 8-bit weights (optional: holds the K-contiguous transpose the
+ *    matrix-core kernels read);
+ *  - else 0.
+ * Without an optional workspace the launch uses the general kernel, which gives the same results far slower.
  * Replaces BaseOperator::GetWorkSpaceSize
  * (device_base.hpp:60; impl/device_gemm_xdl_cshuffle_v3r1.hpp:686-694). */
 size_t wqgemm_workspace_bytes(const wqgemm_problem* p);

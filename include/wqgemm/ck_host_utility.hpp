@@ -120,10 +120,19 @@ struct Tensor
 
     T& operator()(std::size_t i0, std::size_t i1) { return mData[mDesc.Offset(i0, i1)]; }
     const T& operator()(std::size_t i0, std::size_t i1) const { return mData[mDesc.Offset(i0, i1)]; }
+    // 1-D tensors (bias vectors)
+    T& operator()(std::size_t i0) { return mData[i0 * mDesc.GetStrides()[0]]; }
+    const T& operator()(std::size_t i0) const { return mData[i0 * mDesc.GetStrides()[0]]; }
 
     template <typename G>
     void GenerateTensorValue(G g, std::size_t num_thread = 1)
     {
+        if(mDesc.GetNumOfDimension() == 1)
+        {
+            for(std::size_t i0 = 0; i0 < mDesc.GetLengths()[0]; ++i0)
+                (*this)(i0) = g(i0);
+            return;
+        }
         parallel_for_2d([&](std::size_t i0, std::size_t i1) { (*this)(i0, i1) = g(i0, i1); },
                         mDesc.GetLengths()[0], mDesc.GetLengths()[1], num_thread);
     }

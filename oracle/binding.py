@@ -83,6 +83,8 @@ class Checker:
         tail = [C.c_int] if self._threaded else []
         self._fpaintb = sig("fpAintB_gemm_f16", None, [_u16p, _i8p, _u16p, _u16p] + [C.c_int] * 6 + tail)
         self._i8 = sig("gemm_i8_requant", None, [_i8p, _i8p, _i8p] + [C.c_int] * 6 + [C.c_float] + tail)
+        self._i8b = sig("gemm_i8_bias_requant", None,
+                        [_i8p, _i8p, C.c_void_p, _i8p] + [C.c_int] * 6 + [C.c_float, C.c_int] + tail)
         self._bf16 = sig("gemm_bf16_i8", None,
                          [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p] + tail)
         self._f8 = sig("gemm_f8_i8_mm", None, [_u8p, _i8p, _f32p, _f32p, _u16p] + [C.c_int] * 7 + tail)
@@ -123,6 +125,14 @@ class Checker:
     def gemm_i8_requant(self, a, b, M, N, K, lda, ldb, lde, requant, nthreads=None) -> np.ndarray:
         e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.int8)
         self._i8(a.ravel(), b.ravel(), e, M, N, K, lda, ldb, lde, requant, *self._t(nthreads))
+        return e
+
+    def gemm_i8_bias_requant(self, a, b, bias, M, N, K, lda, ldb, lde, requant, relu, nthreads=None) -> np.ndarray:
+        """int32-accumulated int8 GEMM + (Add_)Activation_Mul_Clamp<PassThrough|Relu>; bias = N int32 or None."""
+        e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.int8)
+        pb = np.ascontiguousarray(bias, np.int32) if bias is not None else None
+        self._i8b(a.ravel(), b.ravel(), pb.ctypes.data if pb is not None else None, e, M, N, K, lda, ldb, lde,
+                  requant, int(relu), *self._t(nthreads))
         return e
 
     def gemm_bf16_i8(self, a, b0, b1, M, N, K, lda, b_sk, b_sn, lde, epilogue, d0=None, d1=None,

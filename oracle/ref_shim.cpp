@@ -198,6 +198,35 @@ void ckref_gemm_i8_requant(const int8_t* a, const int8_t* b, int8_t* e, int M, i
     store2(te, e);
 }
 
+// example/14 bias + relu verify path (gemm_xdl_bias_relu_quantization_int8.cpp:97-103,211-229):
+// ReferenceGemm<int8,int8,int32,int32,PT,PT,PT>, then Add_Activation_Mul_Clamp<Act>(e, c, bias(n)) per element;
+// bias == nullptr applies Activation_Mul_Clamp<Act>(e, c).  relu selects Act = Relu, else PassThrough.
+void ckref_gemm_i8_bias_requant(const int8_t* a, const int8_t* b, const int32_t* bias, int8_t* e, int M, int N,
+                                int K, int lda, int ldb, int lde, float requant, int relu)
+{
+    using Ref = ck::tensor_operation::host::ReferenceGemm<int8_t, int8_t, int32_t, int32_t, PT, PT, PT>;
+    auto ta   = load2<int8_t>(a, M, K, lda, 1);
+    auto tb   = load2<int8_t>(b, K, N, 1, ldb);
+    Tensor<int32_t> tc(desc2(M, N, N, 1));
+    auto ref = Ref{};
+    auto inv = ref.MakeInvoker();
+    inv.Run(ref.MakeArgument(ta, tb, tc, PT{}, PT{}, PT{}));
+    for(int m = 0; m < M; ++m)
+        for(int n = 0; n < N; ++n)
+        {
+            int8_t y = 0;
+            if(bias && relu)
+                ew::Add_Activation_Mul_Clamp<ew::Relu>{requant, ew::Relu{}}(y, tc(m, n), bias[n]);
+            else if(bias)
+                ew::Add_Activation_Mul_Clamp<PT>{requant, PT{}}(y, tc(m, n), bias[n]);
+            else if(relu)
+                ew::Activation_Mul_Clamp<ew::Relu>{requant, ew::Relu{}}(y, tc(m, n));
+            else
+                ew::Activation_Mul_Clamp<PT>{requant, PT{}}(y, tc(m, n));
+            e[(size_t)m * lde + n] = y;
+        }
+}
+
 // example/60 verify path: b = Multiply(b0 int8, b1 bhalf scale[n]); c = ReferenceGemm<bhalf,
 // bhalf, float, float, PT,PT,PT>; e = epilogue(c).  B element (k,n) at k*b_sk + n*b_sn.
 // epilogue: 0 PassThrough (float->bhalf), 1 FastGelu<bhalf,float>,

@@ -180,6 +180,19 @@ int8_t wqo_act_mul_clamp_from_float(float requant, float acc)
     return wqo_act_mul_clamp(requant, (int32_t)acc);
 }
 
+/* quantization_operation.hpp:39-45 and :149-156 with Activation = PassThrough or Relu
+ * (unary_element_wise_operation.hpp:409-419: y = x > 0 ? x : 0): the int32 bias is added in int32, the sum goes to
+ * float, through the activation, times requantScale, clamped, and to int8 toward zero. */
+int8_t wqo_add_act_mul_clamp(float requant, int32_t x, int32_t bias, int relu)
+{
+    float y = (float)(x + bias);
+    if(relu)
+        y = y > 0 ? y : 0;
+    y = requant * y;
+    y = y < -128.f ? -128.f : (y > 127.f ? 127.f : y);
+    return (int8_t)y;
+}
+
 /* element_wise_operation.hpp:252-275  MultiplyMultiply: e = cvt(c * d0 * d1), left to right */
 uint16_t wqo_multiply_multiply_f16(float c, float d0, float d1)
 {
@@ -410,6 +423,34 @@ void wqo_gemm_i8_requant(const int8_t* a, const int8_t* b, int8_t* e, int M, int
 {
     i8_ctx x = {a, b, e, K, lda, ldb, lde, requant};
     parallel_mn(i8_requant_mn, &x, M, N, nthreads);
+}
+
+/* example/14_gemm_quantization/gemm_xdl_bias_relu_quantization_int8.cpp:97-103,211-229 verify path:
+ * c = ReferenceGemm<int8,int8,int32,int32,PT,PT,PT> (int32 accumulation, exact), then per element
+ * Add_Activation_Mul_Clamp<Act>(e, c(m,n), bias(n)); bias == NULL is Activation_Mul_Clamp<Act>(e, c(m,n)). */
+typedef struct
+{
+    const int8_t *a, *b;
+    const int32_t* bias;
+    int8_t* e;
+    int K, lda, ldb, lde, relu;
+    float requant;
+} i8b_ctx;
+
+static void i8_bias_requant_mn(void* p, int m, int n)
+{
+    const i8b_ctx* x = (const i8b_ctx*)p;
+    int32_t acc      = 0;
+    for(int k = 0; k < x->K; ++k)
+        acc += (int32_t)x->a[(size_t)m * x->lda + k] * (int32_t)x->b[(size_t)n * x->ldb + k];
+    x->e[(size_t)m * x->lde + n] = wqo_add_act_mul_clamp(x->requant, acc, x->bias ? x->bias[n] : 0, x->relu);
+}
+
+void wqo_gemm_i8_bias_requant(const int8_t* a, const int8_t* b, const int32_t* bias, int8_t* e, int M, int N,
+                              int K, int lda, int ldb, int lde, float requant, int relu, int nthreads)
+{
+    i8b_ctx x = {a, b, bias, e, K, lda, ldb, lde, relu, requant};
+    parallel_mn(i8_bias_requant_mn, &x, M, N, nthreads);
 }
 
 /* example/60_gemm_multi_ABD/gemm_multi_ABD_xdl_fastgelu_bf16_i8.cpp:236-272 verify path:

@@ -167,6 +167,26 @@ def gemm_cases(ref) -> dict:
     out["f8_a"], out["f8_b"], out["f8_d0"], out["f8_d1"] = a8, b4, f0, f1
     out["f8_e_mm"] = ref.gemm_f8_i8_mm(a8, b4, f0, f1, M, N, K, K, K, N, False)
     out["f8_e_mm_gelu"] = ref.gemm_f8_i8_mm(a8, b4, f0, f1, M, N, K, K, K, N, True)
+
+    # ---- int8 requantisation with Relu and/or an int32 bias (example/14 bias + relu verify path) -------------
+    # inputs drawn like the example's: srand(1), then A, B and the bias from GeneratorTensor_2{-128,127} in that order
+    M = N = K = 128
+    a = ref.generator2_i8(M, K, K, 1, -128, 127, seed=1)
+    b = ref.generator2_i8(K, N, 1, K, -128, 127, seed=-1)
+    bias = ref.generator2_i8(1, N, N, 1, -128, 127, seed=-1).astype(np.int32)
+    out["i8b_bias"] = bias
+    for relu in (0, 1):
+        out[f"i8b_e_relu{relu}"] = ref.gemm_i8_bias_requant(a, b, None, M, N, K, K, K, N, 0.03, relu)
+        out[f"i8b_e_bias_relu{relu}"] = ref.gemm_i8_bias_requant(a, b, bias, M, N, K, K, K, N, 0.03, relu)
+    # the small ragged case above with a bias that matters at its accumulator range
+    M, N, K = 40, 24, 96
+    bias_s = rng.integers(-200, 201, N).astype(np.int32)
+    out["i8_small_bias"] = bias_s
+    for relu in (0, 1):
+        out[f"i8_small_e_bias_relu{relu}"] = ref.gemm_i8_bias_requant(
+            out["i8_small_a"], out["i8_small_b"], bias_s, M, N, K, 104, 100, 32, 0.25, relu)
+        out[f"i8_small_e_relu{relu}"] = ref.gemm_i8_bias_requant(
+            out["i8_small_a"], out["i8_small_b"], None, M, N, K, 104, 100, 32, 0.25, relu)
     return out
 
 

@@ -43,6 +43,22 @@ def test_int8_quantization_example():
     assert r.returncode == 0 and "verification: PASS" in r.stdout
 
 
+def test_int8_bias_relu_quantization_example():
+    r = _run(os.path.join(EX, "example_gemm_bias_relu_quantization_int8_gfx950"), 1, 512)
+    assert r.returncode == 0 and "verification: PASS" in r.stdout
+    assert "DeviceGemmBiasQuantization_gfx950" in r.stdout
+
+
+@pytest.mark.parametrize("name,op", [("gemm_xdl_quantization_int8", "DeviceGemmQuantization_gfx950"),
+                                     ("gemm_xdl_bias_relu_quantization_int8", "DeviceGemmBiasQuantization_gfx950")])
+def test_reference_example14_sources_dropin(name, op):
+    """CK's example/14_gemm_quantization XDL sources compiled unmodified (fixed 1024^3 problem): the binary returns 0
+    only if ck::utils::check_err(device, CK's host reference) passed with the default int8 tolerance of 0."""
+    r = _run(os.path.join(EX, "_ref_build", f"example14_{name}_dropin"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Perf:" in r.stdout and op in r.stdout
+
+
 @pytest.mark.parametrize("init", [1, 2])
 def test_reference_example64_source_dropin(init):
     """CK's example/64 binary (argv: verify init time M N K StrideA StrideB StrideC) returns 0

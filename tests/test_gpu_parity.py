@@ -247,12 +247,16 @@ def test_bf16_int8_mfma(port):
     np.testing.assert_array_equal(got, exp)
 
 
-def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None):
+def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None, bias=None, relu=False):
     a_t, b_t = dev(a), dev(b)
     ldc = ldc or N
     e_t = torch.full((M, ldc), 77, dtype=torch.int8, device="cuda")
+    bias_t = dev(np.ascontiguousarray(bias, np.int32)) if bias is not None else None
+    epi = ((capi.EPI_ADD_RELU_MUL_CLAMP if relu else capi.EPI_ADD_ACT_MUL_CLAMP) if bias is not None
+           else (capi.EPI_RELU_MUL_CLAMP if relu else capi.EPI_ACT_MUL_CLAMP))
     p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), None, e_t.data_ptr(), M, N, K, a_dtype=capi.I8,
-                             b_dtype=capi.I8, c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=requant,
+                             b_dtype=capi.I8, c_dtype=capi.I8, epilogue=epi, requant=requant,
+                             d0=bias_t.data_ptr() if bias_t is not None else None,
                              flags=flags, lda=lda, ldb=ldb, ldc=ldc)
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
@@ -299,6 +303,45 @@ def test_int8_requant_golden_ragged_and_large(golden_gemm, port):
     ref = port.gemm_i8_requant(np.ascontiguousarray(a[:64]), b, 64, N, K, K, K, N, 1e-4).reshape(64, N)
     np.testing.assert_array_equal(e[:64], ref)
     assert np.abs(ref.astype(np.int32)).max() < 127 and np.unique(ref).size > 20
+
+
+def test_int8_bias_relu_requant(golden_gemm, port):
+    """Activation_Mul_Clamp<Relu> and Add_Activation_Mul_Clamp<PassThrough | Relu> (example/14's bias + relu
+    variant): golden cases bit-exact on the int8 MFMA kernel and the generic kernel, the example's own 1024^3 size
+    against the checker on a row block."""
+    g = golden_gemm
+    M = N = K = 128
+    a = port.generator2_i8(M, K, K, 1, -128, 127, seed=1)
+    b = port.generator2_i8(K, N, 1, K, -128, 127, seed=-1)
+    for relu in (0, 1):
+        for bias, key in ((None, f"i8b_e_relu{relu}"), (g["i8b_bias"], f"i8b_e_bias_relu{relu}")):
+            e, name = _run_i8(a, b, M, N, K, 0.03, bias=bias, relu=bool(relu))
+            assert name == "wq_gemm_i8_mfma_128"
+            np.testing.assert_array_equal(e.ravel(), g[key])
+            e, name = _run_i8(a, b, M, N, K, 0.03, bias=bias, relu=bool(relu), flags=capi.FLAG_GENERIC)
+            assert name == GENERIC
+            np.testing.assert_array_equal(e.ravel(), g[key])
+        for bias, key in ((None, f"i8_small_e_relu{relu}"), (g["i8_small_bias"], f"i8_small_e_bias_relu{relu}")):
+            e, name = _run_i8(g["i8_small_a"], g["i8_small_b"], 40, 24, 96, 0.25, lda=104, ldb=100, ldc=32, bias=bias,
+                              relu=bool(relu))
+            assert name == GENERIC
+            exp = np.concatenate([g[key], np.zeros(40 * 32 - g[key].size, np.int8)])
+            np.testing.assert_array_equal(e[:, :24], exp.reshape(40, 32)[:, :24])
+    rng = np.random.default_rng(15)
+    M = N = K = 1024
+    a = rng.integers(-128, 128, (M, K)).astype(np.int8)
+    b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    bias = rng.integers(-300000, 300001, N).astype(np.int32)
+    for rq in (0.03, 2e-4):
+        e, name = _run_i8(a, b, M, N, K, rq, bias=bias, relu=True)
+        assert name == "wq_gemm_i8_mfma_128"
+        ref = port.gemm_i8_bias_requant(np.ascontiguousarray(a[:64]), b, bias, 64, N, K, K, K, N, rq, 1).reshape(64, N)
+        np.testing.assert_array_equal(e[:64], ref)
+    assert ref.min() == 0 and np.unique(ref).size > 20
+    # a missing bias pointer is a malformed problem
+    p = capi.fpAintB_problem(1, 1, None, 1, 128, 128, 128, a_dtype=capi.I8, b_dtype=capi.I8, c_dtype=capi.I8,
+                             epilogue=capi.EPI_ADD_RELU_MUL_CLAMP, requant=0.03)
+    assert not capi.is_supported(p)
 
 
 def test_f8_int4_multiply_multiply_generic(golden_gemm):

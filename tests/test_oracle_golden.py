@@ -127,6 +127,30 @@ def test_i8_small_ragged(port, golden_gemm):
     np.testing.assert_array_equal(e, g["i8_small_e"])
 
 
+def test_i8_bias_relu_requant(port, golden_gemm):
+    """example/14's bias + relu verify path: srand(1) inputs (A, B, then the int32 bias) at 128^3, and the small
+    ragged case, for Activation in {PassThrough, Relu} with and without the bias."""
+    g = golden_gemm
+    M = N = K = 128
+    a = port.generator2_i8(M, K, K, 1, -128, 127, seed=1)
+    b = port.generator2_i8(K, N, 1, K, -128, 127, seed=-1)
+    bias = port.generator2_i8(1, N, N, 1, -128, 127, seed=-1).astype(np.int32)
+    np.testing.assert_array_equal(bias, g["i8b_bias"])
+    for relu in (0, 1):
+        np.testing.assert_array_equal(port.gemm_i8_bias_requant(a, b, None, M, N, K, K, K, N, 0.03, relu),
+                                      g[f"i8b_e_relu{relu}"])
+        np.testing.assert_array_equal(port.gemm_i8_bias_requant(a, b, bias, M, N, K, K, K, N, 0.03, relu),
+                                      g[f"i8b_e_bias_relu{relu}"])
+        np.testing.assert_array_equal(
+            port.gemm_i8_bias_requant(g["i8_small_a"], g["i8_small_b"], g["i8_small_bias"], 40, 24, 96, 104, 100, 32,
+                                      0.25, relu), g[f"i8_small_e_bias_relu{relu}"])
+        np.testing.assert_array_equal(
+            port.gemm_i8_bias_requant(g["i8_small_a"], g["i8_small_b"], None, 40, 24, 96, 104, 100, 32, 0.25, relu),
+            g[f"i8_small_e_relu{relu}"])
+    # without Relu and bias, and while the float accumulation of the plain path is exact, both paths agree
+    np.testing.assert_array_equal(g["i8_small_e_relu0"], g["i8_small_e"])
+
+
 def test_bf16_i8_cases(port, golden_gemm):
     g = golden_gemm
     M, N, K = 48, 64, 128

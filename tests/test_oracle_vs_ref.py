@@ -60,3 +60,15 @@ def test_bf16_and_f8_random(port, ref):
     for gelu in (False, True):
         np.testing.assert_array_equal(port.gemm_f8_i8_mm(a8, b4, f0, f1, M, N, K, K, K, N, gelu),
                                       ref.gemm_f8_i8_mm(a8, b4, f0, f1, M, N, K, K, K, N, gelu))
+
+
+def test_i8_bias_requant_random(port, ref):
+    rng = np.random.default_rng(21)
+    for M, N, K, lo, hi, rq in ((9, 17, 50, -128, 128, 0.002), (32, 8, 300, -20, 21, 0.01), (5, 64, 1024, -128, 128, 0.03)):
+        a = rng.integers(lo, hi, (M, K)).astype(np.int8)
+        b = rng.integers(lo, hi, (N, K)).astype(np.int8)
+        bias = rng.integers(-5000, 5001, N).astype(np.int32)
+        for relu in (0, 1):
+            for bs in (None, bias):
+                np.testing.assert_array_equal(port.gemm_i8_bias_requant(a, b, bs, M, N, K, K, K, N, rq, relu),
+                                              ref.gemm_i8_bias_requant(a, b, bs, M, N, K, K, K, N, rq, relu))
