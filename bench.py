@@ -6,6 +6,8 @@
 
 N = 1  : BASELINE config 2 -- fp16 A x packed-int4 B, per-channel fp16 scale, M = N = K = 4096.
          One step = one GEMM launch over one synthetic batch resident in HBM.
+         --config C1 | C3 | C5 runs one of the other single-GPU BASELINE configurations the same way
+         (int8 requant 256^3; bf16 x int8 4096 x 11008 x 4096; fp8 x int4 + MultiplyMultiply + FastGelu 4096^3).
 N > 1  : BASELINE config 4 -- the same GEMM at M = N = 4096, K = 65536, K split across the N
          ranks (one process per GPU), fp32 partials summed with RCCL (reduce-scatter over xGMI),
          convert/epilogue on each rank's rows, all-gather of the fp16 rows.  Total work is fixed
@@ -110,12 +112,198 @@ def pmc_traffic(kernel):
     return summary.get("hbm_bytes_per_launch")
 
 
-def run_single(args):
-    dev = torch.device("cuda", 0)
+PEAK_8BIT_MFMA_TFLOPS = 5000.0  # dense fp8 / int8 MFMA peak of MI355X
+
+
+def _cpu_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(16, cores))
+
+
+def _row_block(run_rows, M, budget_s, probe=4):
+    """Time run_rows(r) (the CPU checker on the first r rows of A) on a block sized for ~budget_s of work."""
+    t0 = time.perf_counter()
+    run_rows(probe)
+    t_cal = time.perf_counter() - t0
+    rows = int(max(8, min(1024, M, (budget_s / max(t_cal, 1e-6)) * probe)))
+    rows -= rows % 8
+    t0 = time.perf_counter()
+    ref = run_rows(rows)
+    return rows, time.perf_counter() - t0, ref
+
+
+def workload_c2(dev):
+    """BASELINE config 2: fp16 A x packed-int4 B, per-channel fp16 scale, 4096^3 (the headline workload)."""
     M = N = K = 4096
     a, q, s, bp = synth_inputs(M, N, K, 11939, dev)
     c = torch.empty((M, N), dtype=torch.float16, device=dev)
     p = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K)
+
+    def clone():
+        a2, b2, c2 = a.clone(), bp.clone(), torch.empty_like(c)
+        return (a2, b2, c2), capi.fpAintB_problem(a2.data_ptr(), b2.data_ptr(), s.data_ptr(), c2.data_ptr(), M, N, K)
+
+    def cpu(budget_s):
+        return cpu_baseline_leg(a, q, s, c, M, N, K, budget_s)
+
+    return {"M": M, "N": N, "K": K, "problem": p, "keep": (a, q, s, bp, c), "clone": clone, "cpu": cpu,
+            "dtype": "f16", "peak": PEAK_FP16_MFMA_TFLOPS, "bytes": algorithmic_bytes(M, N, K), "workspace": None,
+            "workload": "fp16A x int4B GEMM M=N=K=4096, per-channel fp16 scale, fp16 C "
+                        "(example/64_fpAintB_gemm shape class, BASELINE config 2)"}
+
+
+def workload_c1(dev):
+    """BASELINE config 1: int8 x int8 256^3 with Activation_Mul_Clamp(0.03) -- example/14's verification case, the
+    reference's own CPU-runnable configuration.  Inputs uniform over the int8 range; the CPU leg runs the full size."""
+    M = N = K = 256
+    g = torch.Generator(device=dev)
+    g.manual_seed(11939)
+    a = torch.randint(-128, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
+    b = torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8)
+    e = torch.empty((M, N), dtype=torch.int8, device=dev)
+
+    def prob(a_, b_, e_):
+        return capi.fpAintB_problem(a_.data_ptr(), b_.data_ptr(), None, e_.data_ptr(), M, N, K, a_dtype=capi.I8,
+                                    b_dtype=capi.I8, c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=0.03)
+
+    def clone():
+        t = (a.clone(), b.clone(), torch.empty_like(e))
+        return t, prob(*t)
+
+    def cpu(budget_s):
+        from oracle import binding  # the checker: timed baseline and cross-check only
+        port = binding.load_port()
+        cores = _cpu_cores()
+        a_h, b_h = a.cpu().numpy(), b.cpu().numpy()
+        port.gemm_i8_requant(a_h, b_h, M, N, K, K, K, N, 0.03, nthreads=cores)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            ref = port.gemm_i8_requant(a_h, b_h, M, N, K, K, K, N, 0.03, nthreads=cores)
+            reps += 1
+            if time.perf_counter() - t0 > min(budget_s, 3.0):
+                break
+        dt = (time.perf_counter() - t0) / reps
+        ok = bool((e.cpu().numpy().ravel() == ref).all())
+        return {"value": 2.0 * M * N * K / dt / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+                "sample": f"the full 256^3 problem, mean of {reps} runs of {dt * 1e3:.2f} ms",
+                "gpu_rows_match_checker": ok, "max_abs_err": 0.0 if ok else 1.0}
+
+    return {"M": M, "N": N, "K": K, "problem": prob(a, b, e), "keep": (a, b, e), "clone": clone, "cpu": cpu,
+            "dtype": "i8", "peak": PEAK_8BIT_MFMA_TFLOPS, "bytes": 3 * M * N, "workspace": None,
+            "workload": "int8 x int8 GEMM M=N=K=256 + Activation_Mul_Clamp(0.03), int8 out "
+                        "(example/14_gemm_quantization verification size, BASELINE config 1)"}
+
+
+def workload_c3(dev):
+    """BASELINE config 3: bf16 A x int8 B, per-channel bf16 scale, M=4096 N=11008 K=4096 (example/60's arithmetic)."""
+    M, N, K = 4096, 11008, 4096
+    g = torch.Generator(device=dev)
+    g.manual_seed(11939)
+    a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).bfloat16()
+    s = (torch.rand((N,), generator=g, device=dev) * (2.0 ** -6 - 2.0 ** -10) + 2.0 ** -10).bfloat16()
+    b = torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8)
+    c = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+
+    def prob(a_, b_, c_):
+        return capi.fpAintB_problem(a_.data_ptr(), b_.data_ptr(), s.data_ptr(), c_.data_ptr(), M, N, K,
+                                    a_dtype=capi.BF16, b_dtype=capi.I8)
+
+    def clone():
+        t = (a.clone(), b.clone(), torch.empty_like(c))
+        return t, prob(*t)
+
+    def cpu(budget_s):
+        from oracle import binding  # the checker: timed baseline and cross-check only
+        port = binding.load_port()
+        cores = _cpu_cores()
+        a_h = a.view(torch.int16).cpu().numpy().view(np.uint16)
+        b_h = b.cpu().numpy()
+        s_h = s.view(torch.int16).cpu().numpy().view(np.uint16)
+
+        def run_rows(r):
+            return port.gemm_bf16_i8(np.ascontiguousarray(a_h[:r]), b_h, s_h, r, N, K, K, 1, K, N, 0, nthreads=cores)
+
+        rows, dt, ref = _row_block(run_rows, M, budget_s)
+        ref = (ref.reshape(rows, N).astype(np.uint32) << 16).view(np.float32)
+        got = (c[:rows].view(torch.int16).cpu().numpy().view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+        err = np.abs(got - ref)
+        # bf16 output: one truncation step (2^-7 relative) on top of the fp32 summation-order difference
+        ok = bool((err <= 1e-2 * np.abs(ref) + 1e-2).all())
+        return {"value": 2.0 * rows * N * K / dt / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+                "sample": f"rows 0..{rows - 1} of A x all N={N} x full K={K} ({rows}/{M} of the GEMM), {dt:.2f} s; "
+                          f"full-size estimate {dt * M / rows:.0f} s",
+                "gpu_rows_match_checker": ok, "max_abs_err": float(err.max())}
+
+    return {"M": M, "N": N, "K": K, "problem": prob(a, b, c), "keep": (a, b, s, c), "clone": clone, "cpu": cpu,
+            "dtype": "bf16", "peak": PEAK_FP16_MFMA_TFLOPS, "bytes": 2 * M * K + K * N + 2 * N + 2 * M * N,
+            "workspace": None,
+            "workload": "bf16A x int8B GEMM M=4096 N=11008 K=4096, per-channel bf16 scale (Multiply on B), bf16 C "
+                        "(example/60_gemm_multi_ABD arithmetic, BASELINE config 3)"}
+
+
+def workload_c5(dev):
+    """BASELINE config 5: fp8 A x packed-int4 B + MultiplyMultiply + FastGelu, 4096^3.  A holds E4M3 FNUZ bytes of
+    moderate magnitude (no NaN / +-240 codes), the input contract of the fp8 matrix-core kernel."""
+    M = N = K = 4096
+    g = torch.Generator(device=dev)
+    g.manual_seed(11939)
+    a = (torch.randint(24, 88, (M, K), generator=g, device=dev, dtype=torch.int16) +
+         128 * torch.randint(0, 2, (M, K), generator=g, device=dev, dtype=torch.int16)).to(torch.uint8)
+    q = torch.randint(-8, 8, (N, K), generator=g, device=dev, dtype=torch.int8)
+    bp = torch.empty((N, K // 2), dtype=torch.uint8, device=dev)
+    capi.pack_int4(q.data_ptr(), K, K, N, bp.data_ptr(), K // 2, torch.cuda.current_stream().cuda_stream)
+    d0 = torch.rand((N,), generator=g, device=dev) * 2.0 ** -4
+    d1 = torch.rand((M,), generator=g, device=dev)
+    c = torch.empty((M, N), dtype=torch.float16, device=dev)
+    torch.cuda.synchronize()
+
+    def prob(a_, b_, c_):
+        return capi.fpAintB_problem(a_.data_ptr(), b_.data_ptr(), None, c_.data_ptr(), M, N, K, a_dtype=capi.F8_FNUZ,
+                                    c_dtype=capi.F16, epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU,
+                                    d0=d0.data_ptr(), d1=d1.data_ptr(), flags=capi.FLAG_F8_NO_SPECIALS)
+
+    def clone():
+        t = (a.clone(), bp.clone(), torch.empty_like(c))
+        return t, prob(*t)
+
+    def cpu(budget_s):
+        from oracle import binding  # the checker: timed baseline and cross-check only
+        port = binding.load_port()
+        cores = _cpu_cores()
+        a_h, q_h = a.cpu().numpy(), q.cpu().numpy()
+        d0_h, d1_h = d0.cpu().numpy(), d1.cpu().numpy()
+
+        def run_rows(r):
+            return port.gemm_f8_i8_mm(np.ascontiguousarray(a_h[:r]), q_h, d0_h, np.ascontiguousarray(d1_h[:r]), r, N,
+                                      K, K, K, N, True, nthreads=cores)
+
+        rows, dt, ref = _row_block(run_rows, M, budget_s)
+        ref = ref.reshape(rows, N).view(np.float16).astype(np.float32)
+        got = c[:rows].cpu().numpy().view(np.float16).astype(np.float32)
+        err = np.abs(got - ref)
+        ok = bool((err <= 1e-3 + 1e-3 * np.abs(ref)).all())
+        return {"value": 2.0 * rows * N * K / dt / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+                "sample": f"rows 0..{rows - 1} of A x all N={N} x full K={K} ({rows}/{M} of the GEMM), {dt:.2f} s; "
+                          f"full-size estimate {dt * M / rows:.0f} s",
+                "gpu_rows_match_checker": ok, "max_abs_err": float(err.max())}
+
+    return {"M": M, "N": N, "K": K, "problem": prob(a, bp, c), "keep": (a, q, bp, d0, d1, c), "clone": clone,
+            "cpu": cpu, "dtype": "f8", "peak": PEAK_8BIT_MFMA_TFLOPS,
+            "bytes": M * K + K * N // 2 + 4 * (M + N) + 2 * M * N, "workspace": None,
+            "workload": "fp8(E4M3 FNUZ)A x int4B GEMM M=N=K=4096 + MultiplyMultiply(d0[n], d1[m]) + FastGelu, fp16 C "
+                        "(example/65_gemm_multiply_multiply arithmetic, BASELINE config 5)"}
+
+
+WORKLOADS = {"C1": workload_c1, "C2": workload_c2, "C3": workload_c3, "C5": workload_c5}
+
+
+def run_single(args):
+    dev = torch.device("cuda", 0)
+    w = WORKLOADS[args.config](dev)
+    M, N, K, p = w["M"], w["N"], w["K"], w["problem"]
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
@@ -136,7 +324,7 @@ def run_single(args):
     flops = 2.0 * M * N * K
     tflops = flops * args.steps / wall / 1e12
     kern_tflops = flops / (kern_ms * 1e-3) / 1e12
-    nbytes = algorithmic_bytes(M, N, K)
+    nbytes = w["bytes"]
     out = {
         "metric": "TFLOPs + achieved HBM GB/s, fp16A x int4B GEMM at Llama-7B shapes, 1 GPU",
         "value": tflops,
@@ -149,22 +337,22 @@ def run_single(args):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16",
+        "dtype": w["dtype"],
         "data": "synthetic",
-        "config": {"workload": "fp16A x int4B GEMM M=N=K=4096, per-channel fp16 scale, fp16 C "
-                               "(example/64_fpAintB_gemm shape class, BASELINE config 2)",
+        "config": {"workload": w["workload"], "baseline_config": args.config,
                    "M": M, "N": N, "K": K, "kernel": capi.kernel_name(p), "instance": capi.type_string(p)},
         "hbm_gbps_algorithmic": nbytes / (kern_ms * 1e-3) / 1e9,
         "hbm_frac_of_peak": nbytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-        "roofline": {"bound": "mfma", "achieved": kern_tflops, "peak": PEAK_FP16_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": kern_tflops / PEAK_FP16_MFMA_TFLOPS,
-                     "traffic": pmc_traffic(capi.kernel_name(p)), "kernel_ms": kern_ms,
+        "roofline": {"bound": "mfma", "achieved": kern_tflops, "peak": w["peak"],
+                     "unit": "TFLOP/s", "frac": kern_tflops / w["peak"],
+                     "traffic": pmc_traffic(capi.kernel_name(p)) if args.config == "C2" else None,
+                     "kernel_ms": kern_ms,
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes},
     }
     # Outside the timed region: per-launch times (median next to the mean above) and a rotating-buffer pass in
     # the manner of the reference's flush mode (include/ck/host_utility/flush_cache.hpp:107-235): 4 copies of every
-    # operand (302 MB, more than the 256 MiB last-level cache) used round-robin, so no launch finds its inputs
-    # cached by the previous one.
+    # large operand (more than the 256 MiB last-level cache at the 4096-class sizes) used round-robin, so no launch
+    # finds its inputs cached by the previous one.
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(51)]
     evs[0].record(stream)
     for i in range(50):
@@ -173,8 +361,8 @@ def run_single(args):
     torch.cuda.synchronize()
     per_launch = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(50))
     out["roofline"]["kernel_ms_median"] = per_launch[25]
-    copies = [(a.clone(), bp.clone(), torch.empty_like(c)) for _ in range(4)]
-    probs = [capi.fpAintB_problem(x.data_ptr(), y.data_ptr(), s.data_ptr(), z.data_ptr(), M, N, K) for x, y, z in copies]
+    copies = [w["clone"]() for _ in range(4)]
+    probs = [c[1] for c in copies]
     for i in range(40):
         capi.launch(probs[i % 4], None, sp)
     torch.cuda.synchronize()
@@ -185,9 +373,9 @@ def run_single(args):
     torch.cuda.synchronize()
     rot_ms = e0.elapsed_time(e1) / 100
     out["rotating_buffers"] = {"copies": 4, "kernel_ms": rot_ms, "tflops": flops / (rot_ms * 1e-3) / 1e12}
-    del copies
+    del copies, probs
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_leg(a, q, s, c, M, N, K, args.cpu_budget)
+        out["cpu_baseline"] = w["cpu"](args.cpu_budget)
     print(json.dumps(out))
 
 
@@ -303,6 +491,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the baseline")
     ap.add_argument("--splitk-k", type=int, default=65536)
+    ap.add_argument("--config", choices=("C1", "C2", "C3", "C5"), default="C2",
+                    help="1-GPU workload: C2 (default) is the configuration the metric is quoted on; the others are "
+                         "the remaining single-GPU BASELINE configurations, each with its own CPU baseline")
     ap.add_argument("--ramp-launches", type=int, default=1500,
                     help="extra untimed launches before the timed region so the GPU clocks have settled")
     args = ap.parse_args()
