@@ -58,6 +58,18 @@ def main():
             c = torch.empty((M, N), device=dev, dtype=dt)
             emit(f"torch.matmul {tag} (A row-major, B^T: K contiguous)", M, N, K,
                  lambda a=a, b=b, c=c: torch.matmul(a, b.t(), out=c), 2500.0)
+    # the same GEMMs on the benchmark's own value distribution (A ~ U(-1,1), B = int4 weight * per-channel scale,
+    # already dequantised): matrix-core power, and with it the clock, depends on the operand bits
+    g = torch.Generator(device=dev)
+    g.manual_seed(11939)
+    for dt, tag in ((torch.float16, "fp16"), (torch.bfloat16, "bf16")):
+        for (M, N, K) in ((4096, 4096, 4096), (4096, 11008, 4096)):
+            a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).to(dt)
+            sc = torch.rand((N, 1), generator=g, device=dev) * (2.0 ** -4 - 2.0 ** -8) + 2.0 ** -8
+            b = (torch.randint(-8, 8, (N, K), generator=g, device=dev).float() * sc).to(dt)
+            c = torch.empty((M, N), device=dev, dtype=dt)
+            emit(f"torch.matmul {tag}, benchmark value distribution (dequantised int4 weights)", M, N, K,
+                 lambda a=a, b=b, c=c: torch.matmul(a, b.t(), out=c), 2500.0)
     M = N = K = 4096
     a8 = torch.randint(-128, 128, (M, K), device=dev, dtype=torch.int8)
     b8 = torch.randint(-128, 128, (N, K), device=dev, dtype=torch.int8)
