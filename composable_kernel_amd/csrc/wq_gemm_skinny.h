@@ -1,150 +1,206 @@
-// Small-M ("decode") kernel of the weight-quantized GEMM engine: M <= 64 rows of activations against the
+// Small-M ("decode") kernels of the weight-quantized GEMM engine: M <= 64 rows of activations against the
 // whole weight matrix.  The work is one pass over the weights (0.5 or 1 byte each), so the bound is HBM
-// bandwidth, not the matrix core: the kernel is built to keep many 16-byte weight loads in flight per wave
+// bandwidth, not the matrix core: the kernels are built to keep many 16-byte weight loads in flight per CU
 // and to touch every weight byte once.
 //
-//   grid  (N / 64, 1, k_batch), 256 threads: wave w of a workgroup owns the 16 columns 64 bx + 16 w .. +15 and
-//         the K slice of its blockIdx.z; the activations of that slice (all <= 64 rows) are staged once per
-//         workgroup in LDS and shared by the four waves.
+//   grid  (N / (64 NB), 1, k_batch), 256 threads: wave w of a workgroup owns NB blocks of 16 columns starting at
+//         64 NB bx + 16 NB w, and the K slice of its blockIdx.z.  (The library instantiates NB = 1: NB = 2 halves
+//         what the workgroups together re-read of the activations and the LDS fragment reads per weight, and was
+//         measured no faster at M = 32 and 64 -- those sizes are bound by dequantisation + MFMA issue.)
 //   lane  (fr, fq) = (l & 15, l >> 4) streams column fr of its wave: one 16-byte load per "super-step" =
 //         its CH = 32 (int4) or 16 (8-bit) consecutive k, [fq CH, fq CH + CH) of the super-step's 4 CH = 128 or
 //         64 k; word s of the load feeds MFMA k-step s.  (The k order inside a super-step is free as long as the
 //         activation fragment uses the same mapping: physical k of (s, fq, j) is fq CH + 8 s + j.)
+//   A     the activations (they come from L2: M K 2 bytes, read by every workgroup) pass through LDS in chunks of
+//         SPC super-steps, shared by the four waves: the chunk after the current one is fetched into registers
+//         while the current one is multiplied, so the LDS footprint is one chunk (17 - 33 KiB) whatever K is and
+//         several workgroups fit a CU -- that, times the P loads each lane keeps in flight, is the number of
+//         weight bytes in flight that HBM latency asks for.
 //   MFMA  v_mfma_f32_16x16x32 with the weight fragment first: lane holds C[m = 16 mb + fr][n = 4 fq + j]; a
 //         dequantised weight fragment is reused for the up to four 16-row blocks of activations.
-//   split-K across blockIdx.z gives the chip enough workgroups (a 4096 x 4096 int4 matrix is 32 KiB per CU); the
-//   fp32 partial slabs are summed by wq_reduce_finalize.
+//   split-K across blockIdx.z gives the chip enough workgroups when N / 64 is small; the fp32 partial slabs are
+//   summed by wq_reduce_finalize.
 #pragma once
 
 #include "wq_kernels.h"
 
 namespace wq {
 
-// NMB: 16-row blocks of activations computed (1 for M <= 16, else 4; rows beyond M are zero in LDS and never stored).
-// P:   weight loads in flight per lane; the number of super-steps of a K slice must be a multiple of P, which keeps
-//      the loop body free of branches (so the compiler's wait counts leave P - 1 loads in flight and it can hoist
-//      the LDS reads of a super-step over its arithmetic).  The planner picks slices that allow P = 4; P = 1 serves
-//      everything else.
-template <int AK, int BKIND, int NMB, int P>
+// NMB: 16-row blocks of activations computed (1, 2 or 4; rows beyond M are zero in LDS and never stored).
+// NB:  16-column blocks per wave (1 or 2).
+// P:   weight loads in flight per lane (4 or 1); the number of super-steps of a K slice must be a multiple of P,
+//      which keeps the loop body free of data-dependent branches (so the compiler's wait counts leave P - 1 loads
+//      in flight).  The planner picks slices that allow P = 4; P = 1 serves everything else.
+template <int AK, int BKIND, int NMB, int P, int NB>
 __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 {
-    constexpr int CH    = BKIND == B_I4P ? 32 : 16; // k per lane per super-step (16 bytes of weights)
-    constexpr int KS    = 4 * CH;                   // k per super-step
-    constexpr int STEPS = CH / 8;                   // MFMA k-steps per super-step
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int CH     = BKIND == B_I4P ? 32 : 16; // k per lane per super-step (16 bytes of weights)
+    constexpr int KS     = 4 * CH;                   // k per super-step
+    constexpr int STEPS  = CH / 8;                   // MFMA k-steps per super-step
+    constexpr int SPC    = (NMB == 1 || P == 1) ? P : 2; // super-steps per activation chunk
+    constexpr int KC     = SPC * KS;                 // k per activation chunk
+    constexpr int ROWS   = NMB * 16;
+    constexpr int PITCH  = KC * 2 + 16;              // bytes; the 16 spread the rows of a fragment read over the banks
+    constexpr int CPR    = KC / 8;                   // 16-byte pieces per row of a chunk
+    constexpr int PIECES = ROWS * CPR;
+    constexpr int APT    = (PIECES + 255) / 256;     // pieces per thread
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS * PITCH];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr   = lane & 15;
     const int fq   = lane >> 4;
-    const int n0   = blockIdx.x * 64 + wave * 16;
+    const int n0   = blockIdx.x * (64 * NB) + wave * (16 * NB); // column block nb of the wave starts at n0 + 16 nb
 
     const int kz_begin = p.k_begin + blockIdx.z * p.k_per_z;
     const int kz_end   = min(p.k_end, kz_begin + p.k_per_z);
     const int klen     = max(0, kz_end - kz_begin);
     const int nsteps   = klen / KS; // a multiple of P (host-checked)
+    const int nchunks  = nsteps / SPC;
 
-    // ---- weight stream: the first P loads go out before anything else --------------------------------------------
-    const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
-                          (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
-    u4_t raw[P];
+    f4_t acc[NB][NMB];
+#pragma unroll
+    for(int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for(int mb = 0; mb < NMB; ++mb)
+            acc[nb][mb] = f4_t{0.f, 0.f, 0.f, 0.f};
+
     if(nsteps > 0)
     {
+        // ---- weight stream: the first P loads go out before anything else ----------------------------------------
+        const uint8_t* bptr[NB];
+#pragma unroll
+        for(int nb = 0; nb < NB; ++nb)
+            bptr[nb] = (const uint8_t*)p.b + (size_t)(n0 + 16 * nb + fr) * p.ldb_bytes +
+                       (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
+        u4_t raw[P][NB];
 #pragma unroll
         for(int i = 0; i < P; ++i)
-            raw[i] = *(const u4_t*)(bptr + (size_t)i * 64);
-    }
+#pragma unroll
+            for(int nb = 0; nb < NB; ++nb)
+                raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)i * 64);
 
-    // ---- activations of this K slice -> LDS, rows >= M zero-filled; row pitch klen * 2 + 16 bytes ----------------
-    const int pitch = klen * 2 + 16;
-    {
-        const int chunks_per_row = klen / 8; // 16-byte chunks
-        const int total          = NMB * 16 * chunks_per_row;
-        for(int i = threadIdx.x; i < total; i += 256)
+        // ---- activation chunks: piece q = tid + 256 j of a chunk is 16 bytes of row q / CPR ------------------------
+        const uint8_t* a_src[APT];
+        int a_dst[APT];
+        bool a_ok[APT];
+#pragma unroll
+        for(int j = 0; j < APT; ++j)
         {
-            const int row = i / chunks_per_row, ch = i - row * chunks_per_row;
-            u4_t v        = {0u, 0u, 0u, 0u};
-            if(row < p.M)
-                v = *(const u4_t*)((const uint8_t*)p.a + ((size_t)row * p.lda + kz_begin) * 2 + ch * 16);
-            *(u4_t*)(lds + row * pitch + ch * 16) = v;
+            const int q   = threadIdx.x + 256 * j;
+            const int row = q / CPR, ch = q - row * CPR;
+            a_ok[j]       = q < PIECES && row < p.M;
+            a_src[j]      = (const uint8_t*)p.a + ((size_t)(a_ok[j] ? row : 0) * p.lda + kz_begin) * 2 + ch * 16;
+            a_dst[j]      = q < PIECES ? row * PITCH + ch * 16 : -1;
+        }
+        u4_t apre[APT];
+        auto fetch_chunk = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for(int j = 0; j < APT; ++j)
+            {
+                apre[j] = *(const u4_t*)(a_src[j] + (size_t)c * KC * 2);
+                if(!a_ok[j])
+                    apre[j] = u4_t{0u, 0u, 0u, 0u};
+            }
+        };
+        fetch_chunk(0);
+
+        ScaleReg<AK> sc[NB];
+#pragma unroll
+        for(int nb = 0; nb < NB; ++nb)
+            sc[nb].set(p.scale ? ((const uint16_t*)p.scale)[n0 + 16 * nb + fr] : unit_scale_bits<AK>());
+
+        const uint8_t* a_lane = lds + fr * PITCH + fq * CH * 2;
+        for(int t = 0; t < nsteps; t += P)
+        {
+#pragma unroll
+            for(int cc = 0; cc < P / SPC; ++cc)
+            {
+                const int c = t / SPC + cc;
+                __syncthreads(); // every wave is done with the previous chunk
+#pragma unroll
+                for(int j = 0; j < APT; ++j)
+                    if(a_dst[j] >= 0)
+                        *(u4_t*)(lds + a_dst[j]) = apre[j];
+                __syncthreads();
+                // the next chunk travels while this one is multiplied (past the end: the last one again, unused)
+                fetch_chunk(min(c + 1, nchunks - 1));
+#pragma unroll
+                for(int ii = 0; ii < SPC; ++ii)
+                {
+                    const int i   = cc * SPC + ii;
+                    u4_t w[NB];
+                    // prefetch super-step t + i + P; past the end re-load the last one (valid memory, value unused)
+                    const int nxt = min(t + i + P, nsteps - 1);
+#pragma unroll
+                    for(int nb = 0; nb < NB; ++nb)
+                    {
+                        w[nb]      = raw[i][nb];
+                        raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)nxt * 64);
+                    }
+                    u4_t af[STEPS][NMB];
+#pragma unroll
+                    for(int s = 0; s < STEPS; ++s)
+#pragma unroll
+                        for(int mb = 0; mb < NMB; ++mb)
+                            af[s][mb] = *(const u4_t*)(a_lane + (ii * KS + 8 * s) * 2 + mb * 16 * PITCH);
+#pragma unroll
+                    for(int s = 0; s < STEPS; ++s)
+#pragma unroll
+                        for(int nb = 0; nb < NB; ++nb)
+                        {
+                            u4_t wf;
+                            if constexpr(BKIND == B_I4P)
+                                wf = dequant8(sc[nb], w[nb][s], std::integral_constant<int, B_I4P>{});
+                            else
+                            {
+                                const u2_t w8 = {w[nb][2 * s], w[nb][2 * s + 1]};
+                                if constexpr(AK == A_F16)
+                                    wf = dequant8_bytes_f16<BKIND>(sc[nb], w8);
+                                else
+                                    wf = dequant8_bytes_bf16<BKIND>(sc[nb], w8);
+                            }
+#pragma unroll
+                            for(int mb = 0; mb < NMB; ++mb)
+                            {
+                                if constexpr(AK == A_F16)
+                                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                        __builtin_bit_cast(h8_t, wf), __builtin_bit_cast(h8_t, af[s][mb]), acc[nb][mb], 0, 0, 0);
+                                else
+                                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf8_t, wf), __builtin_bit_cast(bf8_t, af[s][mb]), acc[nb][mb], 0, 0, 0);
+                            }
+                        }
+                }
+            }
         }
     }
-    ScaleReg<AK> sc;
-    sc.set(p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>());
-    __syncthreads();
 
-    f4_t acc[NMB];
+    // ---- store: lane holds C[16 mb + fr][n0 + 16 nb + 4 fq .. +3] -------------------------------------------------
 #pragma unroll
-    for(int mb = 0; mb < NMB; ++mb)
-        acc[mb] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-    const uint8_t* a_lane = lds + fr * pitch + fq * CH * 2;
-    for(int t = 0; t < nsteps; t += P)
-    {
+    for(int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for(int i = 0; i < P; ++i)
+        for(int mb = 0; mb < NMB; ++mb)
         {
-            const u4_t w = raw[i];
-            // prefetch super-step t + i + P; past the end re-load the last one (valid memory, value unused)
-            const int nxt = min(t + i + P, nsteps - 1);
-            raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * 64);
-            u4_t af[STEPS][NMB];
-#pragma unroll
-            for(int s = 0; s < STEPS; ++s)
-#pragma unroll
-                for(int mb = 0; mb < NMB; ++mb)
-                    af[s][mb] = *(const u4_t*)(a_lane + ((t + i) * KS + 8 * s) * 2 + mb * 16 * pitch);
-#pragma unroll
-            for(int s = 0; s < STEPS; ++s)
+            const int m = mb * 16 + fr;
+            if(m < p.M)
             {
-                u4_t wf;
-                if constexpr(BKIND == B_I4P)
-                    wf = dequant8(sc, w[s], std::integral_constant<int, B_I4P>{});
+                const int n = n0 + 16 * nb + fq * 4;
+                if(p.partial)
+                    *(f4_t*)((float*)p.c + ((size_t)blockIdx.z * p.M + m) * p.ldc + n) = acc[nb][mb];
                 else
                 {
-                    const u2_t w8 = {w[2 * s], w[2 * s + 1]};
-                    if constexpr(AK == A_F16)
-                        wf = dequant8_bytes_f16<BKIND>(sc, w8);
-                    else
-                        wf = dequant8_bytes_bf16<BKIND>(sc, w8);
-                }
+                    uint16_t o[4];
 #pragma unroll
-                for(int mb = 0; mb < NMB; ++mb)
-                {
-                    if constexpr(AK == A_F16)
-                        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wf),
-                                                                         __builtin_bit_cast(h8_t, af[s][mb]), acc[mb], 0, 0, 0);
-                    else
-                        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, wf),
-                                                                          __builtin_bit_cast(bf8_t, af[s][mb]), acc[mb], 0, 0, 0);
+                    for(int j = 0; j < 4; ++j)
+                        o[j] = cvt_out16(apply_epilogue(p.epi, acc[nb][mb][j], m, n + j), p.epi.c_dtype);
+                    u2_t pk;
+                    pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+                    pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                    *(u2_t*)((uint16_t*)p.c + (size_t)m * p.ldc + n) = pk;
                 }
             }
         }
-    }
-
-    // ---- store: lane holds C[16 mb + fr][n0 + 4 fq .. +3] --------------------------------------------------------
-#pragma unroll
-    for(int mb = 0; mb < NMB; ++mb)
-    {
-        const int m = mb * 16 + fr;
-        if(m < p.M)
-        {
-            const int n = n0 + fq * 4;
-            if(p.partial)
-                *(f4_t*)((float*)p.c + ((size_t)blockIdx.z * p.M + m) * p.ldc + n) = acc[mb];
-            else
-            {
-                uint16_t o[4];
-#pragma unroll
-                for(int j = 0; j < 4; ++j)
-                    o[j] = cvt_out16(apply_epilogue(p.epi, acc[mb][j], m, n + j), p.epi.c_dtype);
-                u2_t pk;
-                pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-                pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-                *(u2_t*)((uint16_t*)p.c + (size_t)m * p.ldc + n) = pk;
-            }
-        }
-    }
 }
 
 // Variant for M <= 16 that needs neither split-K workspace nor a reduce kernel: the four waves of a workgroup

@@ -9,29 +9,20 @@ namespace wq {
 namespace {
 
 template <int AK, int BKIND, int NMB, int P>
-int launch_t(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
+int launch_t(const GemmParams& gp, dim3 grid, hipStream_t s)
 {
-    static bool opted_in[64] = {}; // more than 64 KiB of dynamic LDS must be opted into once per device
-    int dev                  = 0;
-    if(hipGetDevice(&dev) != hipSuccess)
-        return WQ_ERR_HIP;
-    if(dev >= 0 && dev < 64 && !opted_in[dev])
-    {
-        if(hipFuncSetAttribute((const void*)wq_gemm_skinny<AK, BKIND, NMB, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               144 * 1024) != hipSuccess)
-            return WQ_ERR_HIP;
-        opted_in[dev] = true;
-    }
-    hipLaunchKernelGGL((wq_gemm_skinny<AK, BKIND, NMB, P>), grid, dim3(256), lds_bytes, s, gp);
+    hipLaunchKernelGGL((wq_gemm_skinny<AK, BKIND, NMB, P, 1>), grid, dim3(256), 0, s, gp);
     return WQ_OK;
 }
 
 template <int AK, int BKIND>
-int launch_ab(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int nmb, int p)
+int launch_ab(const GemmParams& gp, dim3 grid, hipStream_t s, int nmb, int p)
 {
     if(nmb == 1)
-        return p == 4 ? launch_t<AK, BKIND, 1, 4>(gp, grid, lds_bytes, s) : launch_t<AK, BKIND, 1, 1>(gp, grid, lds_bytes, s);
-    return p == 4 ? launch_t<AK, BKIND, 4, 4>(gp, grid, lds_bytes, s) : launch_t<AK, BKIND, 4, 1>(gp, grid, lds_bytes, s);
+        return p == 4 ? launch_t<AK, BKIND, 1, 4>(gp, grid, s) : launch_t<AK, BKIND, 1, 1>(gp, grid, s);
+    if(nmb == 2)
+        return p == 4 ? launch_t<AK, BKIND, 2, 4>(gp, grid, s) : launch_t<AK, BKIND, 2, 1>(gp, grid, s);
+    return p == 4 ? launch_t<AK, BKIND, 4, 4>(gp, grid, s) : launch_t<AK, BKIND, 4, 1>(gp, grid, s);
 }
 
 template <int AK, int BKIND, int P>
@@ -74,16 +65,16 @@ int launch_skinny_ws(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_by
                          : launch_ws_ab<A_BF16, B_I8>(gp, grid, lds_bytes, s, p);
 }
 
-// nmb: 1 or 4 sixteen-row blocks staged and computed; p: 4 or 1 loads in flight (super-steps per slice % p == 0)
-int launch_skinny(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int nmb, int p)
+// nmb: 1, 2 or 4 sixteen-row blocks of activations; p: 4 or 1 loads in flight (super-steps per slice % p == 0)
+int launch_skinny(int ak, int bk, const GemmParams& gp, dim3 grid, hipStream_t s, int nmb, int p)
 {
     if(ak == A_F16)
-        return bk == B_I4P   ? launch_ab<A_F16, B_I4P>(gp, grid, lds_bytes, s, nmb, p)
-               : bk == B_U8O ? launch_ab<A_F16, B_U8O>(gp, grid, lds_bytes, s, nmb, p)
-                             : launch_ab<A_F16, B_I8>(gp, grid, lds_bytes, s, nmb, p);
-    return bk == B_I4P   ? launch_ab<A_BF16, B_I4P>(gp, grid, lds_bytes, s, nmb, p)
-           : bk == B_U8O ? launch_ab<A_BF16, B_U8O>(gp, grid, lds_bytes, s, nmb, p)
-                         : launch_ab<A_BF16, B_I8>(gp, grid, lds_bytes, s, nmb, p);
+        return bk == B_I4P   ? launch_ab<A_F16, B_I4P>(gp, grid, s, nmb, p)
+               : bk == B_U8O ? launch_ab<A_F16, B_U8O>(gp, grid, s, nmb, p)
+                             : launch_ab<A_F16, B_I8>(gp, grid, s, nmb, p);
+    return bk == B_I4P   ? launch_ab<A_BF16, B_I4P>(gp, grid, s, nmb, p)
+           : bk == B_U8O ? launch_ab<A_BF16, B_U8O>(gp, grid, s, nmb, p)
+                         : launch_ab<A_BF16, B_I8>(gp, grid, s, nmb, p);
 }
 
 } // namespace wq

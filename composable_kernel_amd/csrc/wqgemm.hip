@@ -20,7 +20,7 @@ WQ_DECL_256(0, 0) WQ_DECL_256(0, 1) WQ_DECL_256(0, 2) WQ_DECL_256(1, 0) WQ_DECL_
 #undef WQ_DECL_256
 int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant); // wq_inst_256_f8.hip
 int launch_256_w32(const GemmParams& gp, dim3 grid, hipStream_t s, int ak);    // wq_inst_256_w32.hip
-int launch_skinny(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int nmb, int p); // wq_inst_skinny.hip
+int launch_skinny(int ak, int bk, const GemmParams& gp, dim3 grid, hipStream_t s, int nmb, int p); // wq_inst_skinny.hip
 int launch_skinny_ws(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int p);
 } // namespace wq
 
@@ -202,9 +202,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // Small M (decode-like shapes): HBM-bound, one pass over the weights; its own kernel with split-K for occupancy.
     {
         const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64; // k per super-step of wq_gemm_skinny
-        const int nmb       = p->M <= 16 ? 1 : 4; // 16-row blocks staged in LDS
         const int klen_all  = plan.k_end - plan.k_begin;
-        const int klen_cap  = ((128 * 1024) / (nmb > 0 ? nmb * 16 : 16) - 16) / 2 / ks * ks; // LDS holds the A slice
         const bool eligible = is16(p->a_dtype) && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                               p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 &&
                               klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
@@ -213,7 +211,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         // M <= 16 with the whole K range of the real rows in LDS: four waves split K inside the workgroup, one
         // kernel, no workspace
         if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all % (4 * ks) == 0 && p->N % 16 == 0 &&
-           (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024 && p->N / 16 >= 128) // (larger images cost more than the reduce kernel saves)
+           (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024 && p->N / 16 >= 128 && // (larger images cost more than the reduce kernel saves)
+           klen_all <= 8192) // (a longer K on N / 16 workgroups is better split across the grid)
         {
             plan.route = ROUTE_SKINNY_WS;
             return WQ_OK;
@@ -225,28 +224,30 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                 per = wqgemm_splitk_kread(klen_all, kb, ks);
             else if(!slice)
             {
-                // enough workgroups for two per CU, and A slices that fit LDS
-                const int want = (512 + p->N / 64 - 1) / (p->N / 64);
-                const int need = (klen_all + klen_cap - 1) / klen_cap;
-                kb             = want > need ? want : need;
-                if(kb > klen_all / ks)
-                    kb = klen_all / ks;
-                // slices of whole 4-super-step groups when K allows (the kernel then keeps 4 loads in flight)
-                const int gran = klen_all % (4 * ks) == 0 ? 4 * ks : ks;
+                // Split K for occupancy (about four workgroups per CU), but not beyond the point where writing and
+                // re-reading the fp32 partials (8 kb M N bytes) costs half of what streaming the weights does, and
+                // in slices of whole 4-super-step groups when K allows (the kernel then keeps 4 loads in flight).
+                const int gran       = klen_all % (4 * ks) == 0 ? 4 * ks : ks;
+                const int wgs        = p->N / 64;
+                const long wbytes_k  = p->b_dtype == WQ_I4_PACKED ? klen_all / 2 : klen_all; // weight bytes per column
+                const int kb_occ     = (1024 + wgs - 1) / wgs;
+                const long kb_bytes  = wbytes_k / (16L * p->M);
+                kb                   = kb_occ;
+                if(kb > kb_bytes)
+                    kb = (int)kb_bytes;
                 if(kb > klen_all / gran)
                     kb = klen_all / gran;
+                if(kb < 1)
+                    kb = 1;
                 per = wqgemm_splitk_kread(klen_all, kb, gran);
                 kb  = (klen_all + per - 1) / per; // no empty slices
             }
-            if(per <= klen_cap)
-            {
-                plan.route      = ROUTE_SKINNY;
-                plan.auto_split = !slice && plan.k_batch == 1 && kb > 1;
-                plan.k_batch    = kb;
-                plan.k_per_z    = per;
-                plan.partial    = slice || kb > 1;
-                return WQ_OK;
-            }
+            plan.route      = ROUTE_SKINNY;
+            plan.auto_split = !slice && plan.k_batch == 1 && kb > 1;
+            plan.k_batch    = kb;
+            plan.k_per_z    = per;
+            plan.partial    = slice || kb > 1;
+            return WQ_OK;
         }
     }
     // 8-bit weights stored (K, N) row-major (the B layout of client_example/30_gemm_bf16Aint8B): the matrix-core
@@ -432,14 +433,13 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end, gp.k_per_z = plan.k_per_z;
         gp.partial = plan.partial ? 1 : 0;
         gp.epi     = epilogue_of(p);
-        const int nmb       = p->M <= 16 ? 1 : 4;
+        const int nmb       = p->M <= 16 ? 1 : (p->M <= 32 ? 2 : 4);
         const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64;
-        const int lds_bytes = nmb * 16 * (plan.k_per_z * 2 + 16);
         // 4 loads in flight when every slice is a whole number of 4-super-step groups
         const int klen      = plan.k_end - plan.k_begin;
         const bool by4      = plan.k_per_z % (4 * ks) == 0 && klen % (4 * ks) == 0;
         const dim3 grid(p->N / 64, 1, plan.k_batch);
-        const int rc = wq::launch_skinny(plan.ak, plan.bk, gp, grid, lds_bytes, s, nmb, by4 ? 4 : 1);
+        const int rc = wq::launch_skinny(plan.ak, plan.bk, gp, grid, s, nmb, by4 ? 4 : 1);
         if(rc != WQ_OK)
             return fail(WQ_ERR_HIP, "small-M kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
@@ -587,16 +587,12 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     hipStream_t s = (hipStream_t)stream;
     if(plan.auto_split && !workspace)
     {
-        // the planner's own split-K is an optimisation: without a workspace run one slice, or the general kernel
-        // when the activations of the whole K range do not fit LDS
-        const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, nmb = p->M <= 16 ? 1 : 4;
-        const int klen_cap = ((128 * 1024) / (nmb * 16) - 16) / 2 / ks * ks;
+        // the planner's own split-K is an optimisation: without a workspace the kernel runs the whole K range as
+        // one slice
         plan.auto_split = false;
         plan.k_batch    = 1;
         plan.partial    = false;
         plan.k_per_z    = plan.k_end - plan.k_begin;
-        if(plan.k_per_z > klen_cap)
-            plan.route = ROUTE_GENERIC;
     }
     if(plan.partial && !plan.to_c && !workspace)
         return fail(WQ_ERR_WORKSPACE, "k_batch = %d needs a workspace of %zu bytes", plan.k_batch,

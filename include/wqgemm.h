@@ -128,8 +128,7 @@ int wqgemm_is_supported(const wqgemm_problem* p);
  *  - k_batch*M*N*4 when the caller sets k_batch > 1 (required: the launch fails with WQ_ERR_WORKSPACE
  *    without it);
  *  - kb*M*N*4 when the planner itself splits K for a small-M problem (kb chosen so the grid fills the chip;
- *    optional: without it the launch runs one K slice, or the general kernel when the activations of the
- *    whole K range do not fit LDS);
+ *    optional: without it the launch runs the whole K range as one slice);
  *  - (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
  *    fp16 image of A for the fp16 matrix-core kernel);
  *  - K*N for tile-aligned row-major (K x N) 8-bit weights (optional: holds the K-contiguous transpose the

@@ -720,6 +720,38 @@ def test_small_m_kernel(port, M, a_dtype, b_dtype):
     check_err(bits_to_f32(got[:, :N], a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3)
 
 
+@pytest.mark.parametrize("M,K", [(9, 8192), (33, 4480), (40, 8192), (64, 11008), (20, 192)])
+@pytest.mark.parametrize("a_dtype,b_dtype", [(capi.F16, capi.I4_PACKED), (capi.BF16, capi.I8)])
+def test_small_m_kernel_long_k(port, M, K, a_dtype, b_dtype):
+    """Long and odd K ranges: the activations pass through LDS chunk by chunk, so K is not bounded by LDS; K that is
+    not a whole number of 4-super-step groups runs with one load in flight; with and without a workspace."""
+    if b_dtype == capi.I4_PACKED and K % 128:
+        K = K // 128 * 128 + 128
+    rng = np.random.default_rng(M * K + b_dtype)
+    N = 128
+    lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
+    q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+    b = pack_on_device(q, K, N) if b_dtype == capi.I4_PACKED else q
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+
+    def ref(a, s):
+        if a_dtype == capi.F16:
+            return port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+        return port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+
+    a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+    s = cvt(rng.integers(1, 3, N).astype(np.float32))
+    exp = ref(a, s)
+    for kw in (dict(), dict(use_workspace=False), dict(k_batch=2)):
+        got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=SKINNY, **kw)
+        np.testing.assert_array_equal(got, exp)
+    a = cvt(rng.uniform(-1, 1, (M, K)))
+    s = cvt(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    tol = 1e-3 if a_dtype == capi.F16 else 1e-2
+    got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=SKINNY)
+    check_err(bits_to_f32(got, a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3 * max(1.0, (K / 4096) ** 0.5))
+
+
 @pytest.mark.parametrize("M", [1, 3, 16])
 @pytest.mark.parametrize("a_dtype,b_dtype,K", [(capi.F16, capi.I4_PACKED, 1024), (capi.F16, capi.I4_PACKED, 1536),
                                                (capi.BF16, capi.I8, 1024), (capi.BF16, capi.I4_PACKED, 512),
