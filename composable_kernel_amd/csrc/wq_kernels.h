@@ -74,7 +74,8 @@ __device__ __forceinline__ void tile_epilogue_k(const GemmParams& p, const f4_t 
     for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for(int mt = 0; mt < MT; ++mt)
-            store_c4<KIND, BF16>(p.epi, p.c, p.ldc, acc[nt][mt], m_base + mt * RSTEP + fr, n_base + nt * CSTEP + fq * 4);
+            if(m_base + mt * RSTEP + fr < p.M) // the last row tile of the 128-tile kernel may be partial
+                store_c4<KIND, BF16>(p.epi, p.c, p.ldc, acc[nt][mt], m_base + mt * RSTEP + fr, n_base + nt * CSTEP + fq * 4);
 }
 
 template <int NT, int MT, int RSTEP = 16, int CSTEP = 16>
@@ -88,7 +89,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
         for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for(int mt = 0; mt < MT; ++mt)
-                *(f4_t*)(slab + (size_t)(m_base + mt * RSTEP + fr) * p.ldc + n_base + nt * CSTEP + fq * 4) = acc[nt][mt];
+                if(m_base + mt * RSTEP + fr < p.M)
+                    *(f4_t*)(slab + (size_t)(m_base + mt * RSTEP + fr) * p.ldc + n_base + nt * CSTEP + fq * 4) = acc[nt][mt];
         return;
     }
     const bool bf = p.epi.c_dtype == 1;
@@ -201,7 +203,7 @@ __device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// 128 x 128 x 64 MFMA kernel
+// 128 x 128 x 64 MFMA kernel (any M >= 1: the last row tile may be partial; N and K in whole tiles)
 // ---------------------------------------------------------------------------------------------
 template <int AK, int BKIND>
 struct Mfma128
@@ -267,7 +269,8 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     {
         const int row   = (wave * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (row & 7);
-        a_src[i] = (const uint8_t*)p.a + ((size_t)(m0 + row) * p.lda + kz_begin) * 2 + chunk * 16;
+        // rows past M (a partial last row tile) re-read row M - 1: valid memory, results never stored
+        a_src[i] = (const uint8_t*)p.a + ((size_t)min(m0 + row, p.M - 1) * p.lda + kz_begin) * 2 + chunk * 16;
     }
     // B tile: 128 columns x B_ROW_BYTES.
     constexpr int B_CHUNKS = T::B_ROW_BYTES / 16;              // 16-byte chunks per column: 2 or 4

@@ -70,7 +70,7 @@ struct Plan
     int k_per_z   = 0;
     bool partial  = false; // main kernel writes fp32 partial slabs
     bool to_c     = false; // ... directly into p->c (multi-GPU slice) instead of the workspace
-    bool auto_split = false; // small-M kernel: split-K chosen by the planner, needs (and is dropped without) a workspace
+    bool auto_split = false; // split-K chosen by the planner (small-M kernel, short grids of the 128-tile kernel): needs, and is dropped without, a workspace
     bool via_colb = false; // row-major 8-bit B: transpose into the workspace, then the K-contiguous matrix-core kernels
     bool via_f16  = false; // fp8 FNUZ activations: convert to fp16 in the workspace, then the fp16 MFMA kernel
 };
@@ -189,11 +189,11 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     plan.ak = p->a_dtype == WQ_BF16 ? wq::A_BF16 : wq::A_F16;
     plan.bk = p->b_dtype == WQ_I4_PACKED ? wq::B_I4P : (p->b_dtype == WQ_U8_OFFSET ? wq::B_U8O : wq::B_I8);
 
-    // The tiled MFMA kernel needs whole tiles, K-contiguous operands and 16-byte aligned rows;
-    // everything else goes to the generic kernel.
+    // The tiled MFMA kernel needs whole tiles along N and K (any M: its last row tile may be partial), K-contiguous
+    // operands and 16-byte aligned rows; everything else goes to the generic kernel.
     const int b_row_align = p->b_dtype == WQ_I4_PACKED ? 32 : 16; // ldb elements per 16 bytes
     const bool tiled = is16(p->a_dtype) && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
-                       p->M % 128 == 0 && p->N % 128 == 0 && plan.k_begin % 64 == 0 &&
+                       p->N % 128 == 0 && plan.k_begin % 64 == 0 &&
                        plan.k_per_z % 64 == 0 && (plan.k_end - plan.k_begin) % 64 == 0 &&
                        p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
@@ -254,7 +254,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // kernels want K contiguous, so the launch first transposes B into the workspace (HBM-bound, 2 K N bytes);
     // without a workspace the general kernel runs.
     if(plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) && is16(p->a_dtype) && !plan.partial &&
-       p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_ROW_MAJOR && p->b_dtype != WQ_I4_PACKED && p->M % 128 == 0 &&
+       p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_ROW_MAJOR && p->b_dtype != WQ_I4_PACKED &&
        p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % 16 == 0 && p->ldc % 4 == 0 &&
        (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0)
     {
@@ -273,7 +273,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // FNUZ bytes without that promise: exact in every encoding through an fp16 image of A in the workspace and
     // the fp16 kernels with a unit weight scale (falls back to the general kernel when no workspace is given).
     if(p->a_dtype == WQ_F8_FNUZ && plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) &&
-       !plan.partial && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->M % 128 == 0 &&
+       !plan.partial && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
        p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
        (uintptr_t)p->a % 8 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
     {
@@ -288,10 +288,32 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256))
             plan.route = ROUTE_MFMA256;
     }
+    // Few tiles (a short M against a narrow N) leave most CUs idle: split K across blockIdx.z when the caller has not,
+    // up to about one workgroup per CU and at least four K tiles per slice.  Needs (and is dropped without) a workspace.
+    if(plan.route == ROUTE_MFMA128 && !plan.partial && !plan.via_f16 && !plan.via_colb && !(p->flags & WQ_FLAG_TILE_128))
+    {
+        const int wgs  = ((p->M + 127) / 128) * (p->N / 128);
+        const int klen = plan.k_end - plan.k_begin;
+        int kb         = 256 / wgs;
+        if(kb > klen / 256)
+            kb = klen / 256;
+        if(wgs < 128 && kb > 1)
+        {
+            const int per = wqgemm_splitk_kread(klen, kb, 64);
+            kb            = (klen + per - 1) / per;
+            if(kb > 1)
+            {
+                plan.auto_split = true;
+                plan.k_batch    = kb;
+                plan.k_per_z    = per;
+                plan.partial    = true;
+            }
+        }
+    }
     if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)
         return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs M and N to be multiples of 256 and tile-aligned operands");
     if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_MFMA128)
-        return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_128 needs M and N to be multiples of 128 and tile-aligned operands");
+        return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_128 needs N to be a multiple of 128 and tile-aligned operands");
     return WQ_OK;
 }
 
@@ -357,7 +379,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_end     = plan.k_end;
         gp.k_per_z   = plan.k_per_z;
         gp.partial   = plan.partial ? 1 : 0;
-        gp.tiles_m   = p->M / tile;
+        gp.tiles_m   = (p->M + tile - 1) / tile;
         gp.tiles_n   = p->N / tile;
         gp.epi       = epilogue_of(p);
         gp.direct_store = (p->flags & WQ_FLAG_DIRECT_STORE) ? 1 : 0;

@@ -34,9 +34,14 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     M, K = x.shape
     N = scale.shape[0]
     x = x.contiguous()
-    # up to 64 rows go to the small-M kernel as they are; beyond that the matrix-core kernels take whole 128-row
-    # tiles, so the rows of a ragged batch are padded
-    Mp = (M + 127) // 128 * 128 if (M > 64 and N % 128 == 0 and K % 64 == 0) else M
+    # Any M runs as it is (small-M kernel up to 64 rows, 128-tile kernel with a partial last row tile beyond).  Only
+    # where the faster 256-tile kernel would take the padded problem (whole 256-row tiles, at least 128 of them) are
+    # the rows of a ragged batch padded.
+    Mp = M
+    if M > 64 and M % 256 and N % 256 == 0 and K % 64 == 0:
+        m256 = (M + 255) // 256 * 256
+        if (m256 // 256) * (N // 256) >= 128:
+            Mp = m256
     if Mp != M:
         xp = torch.zeros((Mp, K), dtype=x.dtype, device=x.device)
         xp[:M] = x

@@ -127,7 +127,8 @@ int wqgemm_is_supported(const wqgemm_problem* p);
 /* Bytes of device workspace wqgemm_launch can use:
  *  - k_batch*M*N*4 when the caller sets k_batch > 1 (required: the launch fails with WQ_ERR_WORKSPACE
  *    without it);
- *  - kb*M*N*4 when the planner itself splits K for a small-M problem (kb chosen so the grid fills the chip;
+ *  - kb*M*N*4 when the planner itself splits K (small-M problems, and short grids of the 128-tile kernel; kb chosen
+ *    so the grid fills the chip;
  *    optional: without it the launch runs the whole K range as one slice);
  *  - (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
  *    fp16 image of A for the fp16 matrix-core kernel);

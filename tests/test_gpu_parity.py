@@ -536,16 +536,19 @@ def test_full_size_c2_properties(port):
     rows = slice(1000, 1032)
     exp = port.fpAintB_gemm_f16(np.ascontiguousarray(a[rows]), q, s, 32, N, K, K, K, N).reshape(32, N)
     check_err(bits_to_f32(got[rows], capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
-    # independent HIP path: generic kernel (bit-exact with the checker at small sizes) on a row block
-    # whose M = 96 is not a tile multiple, so the dispatcher must pick it
+    # independent HIP path: generic kernel (bit-exact with the checker at small sizes) on a 96-row block; the same
+    # block through the dispatcher's own choice for a short, ragged M (128-tile kernel, planner-chosen split-K)
     a96 = np.ascontiguousarray(a[2048:2048 + 96])
-    gen = run_fpaintb(a96, bp, s, 96, N, K, expect_kernel=GENERIC)
+    gen = run_fpaintb(a96, bp, s, 96, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
     check_err(bits_to_f32(got[2048:2048 + 96], capi.F16), bits_to_f32(gen, capi.F16), 1e-3, 1e-3)
+    rag = run_fpaintb(a96, bp, s, 96, N, K, expect_kernel=MFMA)
+    check_err(bits_to_f32(rag, capi.F16), bits_to_f32(gen, capi.F16), 1e-3, 1e-3)
     # integer-valued inputs at full size: the MFMA kernel must equal the generic kernel bit for bit
     ai = f16_bits(np.round(rng.uniform(-1, 1, (M, K))))
     si = f16_bits(rng.integers(1, 3, N).astype(np.float32))
     got = run_fpaintb(ai, bp, si, M, N, K, expect_kernel=MFMA256)
-    gen = run_fpaintb(np.ascontiguousarray(ai[512:512 + 96]), bp, si, 96, N, K, expect_kernel=GENERIC)
+    gen = run_fpaintb(np.ascontiguousarray(ai[512:512 + 96]), bp, si, 96, N, K, flags=capi.FLAG_GENERIC,
+                      expect_kernel=GENERIC)
     # ... and the 128-tile kernel on the same full-size problem
     got128 = run_fpaintb(ai, bp, si, M, N, K, flags=capi.FLAG_TILE_128, expect_kernel=MFMA)
     np.testing.assert_array_equal(got128, got)
@@ -718,6 +721,46 @@ def test_small_m_kernel(port, M, a_dtype, b_dtype):
     got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, ldc=N + 8, expect_kernel=SKINNY)
     assert (got[:, N:] == 0x7BFF).all()
     check_err(bits_to_f32(got[:, :N], a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3)
+
+
+@pytest.mark.parametrize("M", [65, 100, 128, 200, 333])
+@pytest.mark.parametrize("a_dtype,b_dtype", [(capi.F16, capi.I4_PACKED), (capi.BF16, capi.I8), (capi.F16, capi.U8_OFFSET)])
+def test_ragged_m_on_the_128_tile_kernel(port, M, a_dtype, b_dtype):
+    """Any M > 64 runs on the 128-tile matrix-core kernel: rows past M in the last row tile are neither read from
+    beyond A nor stored (poisoned rows after C stay intact).  Short grids get a planner-chosen split-K when a workspace
+    is given and run as one slice without it."""
+    rng = np.random.default_rng(31 * M + b_dtype)
+    N, K = 256, 1024
+    lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
+    q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+    if b_dtype == capi.I4_PACKED:
+        b = pack_on_device(q, K, N)
+    elif b_dtype == capi.U8_OFFSET:
+        b = (q.astype(np.int16) + 128).astype(np.uint8)
+    else:
+        b = q
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+
+    def ref(a, s):
+        if a_dtype == capi.F16:
+            return port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+        return port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+
+    a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+    s = cvt(rng.integers(1, 3, N).astype(np.float32))
+    exp = ref(a, s)
+    for kw in (dict(), dict(use_workspace=False), dict(k_batch=3), dict(flags=capi.FLAG_TILE_128)):
+        got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=MFMA, **kw)
+        np.testing.assert_array_equal(got, exp)
+    a = cvt(rng.uniform(-1, 1, (M, K)))
+    s = cvt(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    tol = 1e-3 if a_dtype == capi.F16 else 1e-2
+    got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, epilogue=capi.EPI_FASTGELU, ldc=N + 8,
+                      expect_kernel=MFMA)
+    assert (got[:, N:] == 0x7BFF).all()
+    gen = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, epilogue=capi.EPI_FASTGELU, flags=capi.FLAG_GENERIC,
+                      expect_kernel=GENERIC)
+    check_err(bits_to_f32(got[:, :N], a_dtype), bits_to_f32(gen, a_dtype), tol, 1e-3)
 
 
 @pytest.mark.parametrize("M,K", [(9, 8192), (33, 4480), (40, 8192), (64, 11008), (20, 192)])
