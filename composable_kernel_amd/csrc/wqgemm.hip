@@ -297,7 +297,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         int kb         = 256 / wgs;
         if(kb > klen / 256)
             kb = klen / 256;
-        if(wgs < 128 && kb > 1)
+        if(wgs <= 128 && kb > 1)
         {
             const int per = wqgemm_splitk_kread(klen, kb, 64);
             kb            = (klen + per - 1) / per;
