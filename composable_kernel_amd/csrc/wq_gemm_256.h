@@ -175,7 +175,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
     {
         const int row   = (wave * T::A_DMA + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (row & 7);
-        a_src[i] = (const uint8_t*)p.a + ((size_t)(m0 + row) * p.lda + kz_begin) * 2 + chunk * 16;
+        // rows past M (a partial last row tile) re-read row M - 1: valid memory, results never stored
+        a_src[i] = (const uint8_t*)p.a + ((size_t)min(m0 + row, p.M - 1) * p.lda + kz_begin) * 2 + chunk * 16;
     }
     constexpr int B_CHUNKS         = T::B_ROW_BYTES / 16; // 2 or 4
     constexpr int B_COLS_PER_INSTR = 64 / B_CHUNKS;       // 32 or 16

@@ -165,7 +165,8 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
         const int r   = wave * 32 + 2 * i + (lane >> 5);
         const int c16 = lane & 31;
         const u4_t v  = *(const u4_t*)(lds + r * kCTilePitch + c16 * 16);
-        *(u4_t*)(cg + (size_t)r * p.ldc + c16 * 8) = v;
+        if(m0 + r < p.M) // the last row tile may be partial
+            *(u4_t*)(cg + (size_t)r * p.ldc + c16 * 8) = v;
     }
 }
 

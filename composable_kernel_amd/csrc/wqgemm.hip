@@ -281,10 +281,12 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         plan.ak      = wq::A_F16;
         plan.route   = ROUTE_MFMA128;
     }
-    if(plan.route == ROUTE_MFMA128 && p->M % 256 == 0 && p->N % 256 == 0 && p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
+    // (the last row tile may be partial, as in the 128-tile kernel; the 32x32-MFMA variant keeps whole tiles)
+    if(plan.route == ROUTE_MFMA128 && (p->M % 256 == 0 || !(p->flags & WQ_FLAG_MFMA_32X32)) && p->N % 256 == 0 &&
+       p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
-        const long wgs = (long)(p->M / 256) * (p->N / 256) * plan.k_batch;
+        const long wgs = (long)((p->M + 255) / 256) * (p->N / 256) * plan.k_batch;
         if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256))
             plan.route = ROUTE_MFMA256;
     }
@@ -311,7 +313,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         }
     }
     if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)
-        return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs M and N to be multiples of 256 and tile-aligned operands");
+        return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs N to be a multiple of 256 and tile-aligned operands");
     if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_MFMA128)
         return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_128 needs N to be a multiple of 128 and tile-aligned operands");
     return WQ_OK;

@@ -34,27 +34,16 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     M, K = x.shape
     N = scale.shape[0]
     x = x.contiguous()
-    # Any M runs as it is (small-M kernel up to 64 rows, 128-tile kernel with a partial last row tile beyond).  Only
-    # where the faster 256-tile kernel would take the padded problem (whole 256-row tiles, at least 128 of them) are
-    # the rows of a ragged batch padded.
-    Mp = M
-    if M > 64 and M % 256 and N % 256 == 0 and K % 64 == 0:
-        m256 = (M + 255) // 256 * 256
-        if (m256 // 256) * (N // 256) >= 128:
-            Mp = m256
-    if Mp != M:
-        xp = torch.zeros((Mp, K), dtype=x.dtype, device=x.device)
-        xp[:M] = x
-        x = xp
-    y = torch.empty((Mp, N), dtype=x.dtype, device=x.device)
-    p = capi.fpAintB_problem(x.data_ptr(), weight.data_ptr(), scale.data_ptr(), y.data_ptr(), Mp, N, K,
+    # any M runs as it is: small-M kernel up to 64 rows, the tile kernels with a partial last row tile beyond
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    p = capi.fpAintB_problem(x.data_ptr(), weight.data_ptr(), scale.data_ptr(), y.data_ptr(), M, N, K,
                              a_dtype=_DT[x.dtype], b_dtype=capi.I4_PACKED if bits == 4 else capi.I8,
                              epilogue=_EPILOGUES[epilogue], d0=bias.data_ptr() if bias is not None else None)
-    nbytes = capi.workspace_bytes(p)  # optional scratch (the small-M kernel's split-K partials)
+    nbytes = capi.workspace_bytes(p)  # optional scratch (the planner's split-K partials)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
         capi.launch(p, ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
-    return y[:M] if Mp != M else y
+    return y
 
 
 @fpaintb_linear.register_fake

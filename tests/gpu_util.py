@@ -41,7 +41,9 @@ def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b
     b_t = b_dev_bytes if isinstance(b_dev_bytes, torch.Tensor) else dev(b_dev_bytes)
     s_t = dev(scale_bits) if scale_bits is not None else None
     ldc = ldc or N
-    c_t = torch.full((M, ldc), 0x7BFF, dtype=torch.int16, device="cuda")  # poison
+    # poison, with guard rows after the M real ones: a kernel that stores rows of a partial last tile is caught
+    guard = 64 if M % 256 else 0
+    c_t = torch.full((M + guard, ldc), 0x7BFF, dtype=torch.int16, device="cuda")
     keep = [a_t, b_t, s_t, c_t]
     d0_t = dev(d0) if d0 is not None else None
     d1_t = dev(d1) if d1 is not None else None
@@ -62,7 +64,9 @@ def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b
     stream = torch.cuda.current_stream().cuda_stream
     capi.launch(p, ws.data_ptr() if ws is not None else None, stream)
     torch.cuda.synchronize()
-    return host_u16(c_t)
+    out = host_u16(c_t)
+    assert (out[M:] == 0x7BFF).all(), "rows past M were written"
+    return out[:M]
 
 
 def pack_on_device(q: np.ndarray, K: int, N: int) -> torch.Tensor:

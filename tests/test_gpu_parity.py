@@ -763,6 +763,35 @@ def test_ragged_m_on_the_128_tile_kernel(port, M, a_dtype, b_dtype):
     check_err(bits_to_f32(got[:, :N], a_dtype), bits_to_f32(gen, a_dtype), tol, 1e-3)
 
 
+@pytest.mark.parametrize("M", [257, 300, 700])
+@pytest.mark.parametrize("a_dtype,b_dtype", [(capi.F16, capi.I4_PACKED), (capi.BF16, capi.I8)])
+def test_ragged_m_on_the_256_tile_kernel(port, M, a_dtype, b_dtype):
+    """The 256-tile kernel with a partial last row tile (LDS-staged and direct-store epilogues, split-K): bit-exact on
+    integer inputs, rows after C untouched."""
+    rng = np.random.default_rng(17 * M + b_dtype)
+    N, K = 512, 512
+    lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
+    q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+    b = pack_on_device(q, K, N) if b_dtype == capi.I4_PACKED else q
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+
+    def ref(a, s):
+        if a_dtype == capi.F16:
+            return port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+        return port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+
+    a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+    s = cvt(rng.integers(1, 3, N).astype(np.float32))
+    exp = ref(a, s)
+    for kw in (dict(flags=capi.FLAG_TILE_256), dict(flags=capi.FLAG_TILE_256 | capi.FLAG_DIRECT_STORE),
+               dict(flags=capi.FLAG_TILE_256, k_batch=2), dict(flags=capi.FLAG_TILE_256, ldc=N + 8)):
+        got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=MFMA256, **kw)
+        if "ldc" in kw:
+            assert (got[:, N:] == 0x7BFF).all()
+            got = got[:, :N]
+        np.testing.assert_array_equal(got, exp)
+
+
 @pytest.mark.parametrize("M,K", [(9, 8192), (33, 4480), (40, 8192), (64, 11008), (20, 192)])
 @pytest.mark.parametrize("a_dtype,b_dtype", [(capi.F16, capi.I4_PACKED), (capi.BF16, capi.I8)])
 def test_small_m_kernel_long_k(port, M, K, a_dtype, b_dtype):
@@ -868,3 +897,39 @@ def test_torch_linear_over_packed_weights(tmp_path, bits, dt):
     assert torch.allclose(ys.cpu().double(), xs.cpu().double() @ wd.T, rtol=tol, atol=tol)
     # registered as a dispatcher operator (usable from torch.compile graphs through its fake implementation)
     assert torch.ops.wqgemm.fpaintb_linear is not None
+
+
+def test_launch_is_graph_capturable(port):
+    """wqgemm_launch neither allocates nor synchronises, so a stream capture can record it: a small-M problem with the
+    planner's split-K (two kernels and a workspace) and a 256-tile problem are captured into one HIP graph, replayed
+    on fresh inputs, and must give the results of plain launches."""
+    rng = np.random.default_rng(99)
+    cases = []
+    for (M, N, K) in ((8, 256, 2048), (256, 256, 512)):
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        bp = pack_on_device(q, K, N)
+        a = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+        s = f16_bits(rng.integers(1, 3, N).astype(np.float32))
+        exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+        a_t, s_t = dev(np.zeros_like(a)), dev(s)
+        c_t = torch.zeros((M, N), dtype=torch.int16, device="cuda")
+        p = capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), c_t.data_ptr(), M, N, K,
+                                 flags=capi.FLAG_TILE_256 if M == 256 else 0)
+        nbytes = capi.workspace_bytes(p)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+        cases.append((p, ws if nbytes else None, a, a_t, c_t, exp, bp, s_t))
+    assert cases[0][1] is not None and capi.kernel_name(cases[0][0]) == SKINNY
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sp = torch.cuda.current_stream().cuda_stream
+        for p, ws, *_ in cases:
+            capi.launch(p, ws.data_ptr() if ws is not None else None, sp)
+    for _, _, a, a_t, c_t, exp, *_ in cases:  # inputs arrive after the capture
+        a_t.copy_(torch.from_numpy(a.view(np.int16)).cuda().view(a_t.dtype))
+        c_t.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for _, _, a, a_t, c_t, exp, *_ in cases:
+        np.testing.assert_array_equal(c_t.cpu().numpy().view(np.uint16), exp)

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--b", default="i4", choices=("i4", "i8"))
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008,8192x8192,28672x8192,8192x28672")
     ap.add_argument("--ms", default="1,4,16,32,64")
+    ap.add_argument("--graph", action="store_true",
+                    help="time replays of a HIP graph holding 40 launches (no per-launch host work) instead of plain launches")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
@@ -71,10 +73,24 @@ def main():
             wsp = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
+            graph = None
+            if args.graph:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    cs = torch.cuda.current_stream().cuda_stream
+                    for i in range(40):
+                        capi.launch(probs[i % copies], wsp.data_ptr() if nb else None, cs)
+
             def run(n):
                 e0.record(stream)
-                for i in range(n):
-                    capi.launch(probs[i % copies], wsp.data_ptr() if nb else None, sp)
+                if graph is not None:
+                    for _ in range(max(1, n // 40)):
+                        graph.replay()
+                    n = max(1, n // 40) * 40
+                else:
+                    for i in range(n):
+                        capi.launch(probs[i % copies], wsp.data_ptr() if nb else None, sp)
                 e1.record(stream)
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / n
@@ -84,7 +100,8 @@ def main():
             nbytes = wbytes + 2 * M * K + 2 * M * N + 2 * N
             line = {"N": N, "K": K, "M": M, "b": args.b, "kernel": capi.kernel_name(probs[0]), "us": ms * 1e3,
                     "algorithmic_bytes": nbytes, "hbm_gbps": nbytes / (ms * 1e-3) / 1e9,
-                    "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM, "weight_copies_rotated": copies}
+                    "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM, "weight_copies_rotated": copies,
+                    "hip_graph": bool(args.graph)}
             print(json.dumps(line), flush=True)
             lines.append(line)
         del ws
