@@ -133,7 +133,10 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
     // swizzle depends on bits 1 and 2 of the row only, so the lane offset is the same for every i.
     // B: instruction i moves columns 16 (2 w + i) .. +15 (lane -> column lane / 4, chunk lane % 4); bit 3 of the
     // column is bit 5 of the lane.
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0x7FFFFFFF, 0x00020000);
+    // The activation resource ends with the last byte of row M - 1: the rows a partial last row tile has past M are
+    // out of range, which a buffer load answers without touching memory (their results are never stored).
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.K), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, 0x7FFFFFFF, 0x00020000);
     uint32_t a_run[T::A_DMA], b_run[T::B_DMA];
 #pragma unroll

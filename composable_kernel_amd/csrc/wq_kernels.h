@@ -145,11 +145,12 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
         for(int mt = 0; mt < MT; ++mt)
         {
             const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
+            const int m = min(m0 + r, p.M - 1); // rows of a partial last tile past M: keep per-row operand reads in range
             uint16_t o[4];
 #pragma unroll
             for(int j = 0; j < 4; ++j)
             {
-                const float y = apply_epilogue_k<KIND>(p.epi, acc[nt][mt][j], m0 + r, n0 + c + j);
+                const float y = apply_epilogue_k<KIND>(p.epi, acc[nt][mt][j], m, n0 + c + j);
                 o[j]          = BF16 ? f32_to_bf16_trunc(y) : __builtin_bit_cast(uint16_t, (_Float16)y);
             }
             u2_t pk;

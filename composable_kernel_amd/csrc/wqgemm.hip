@@ -265,7 +265,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // FNUZ bytes qualify only when the caller excludes the three encodings E4M3FN cannot express.
     const bool is_f8 = p->a_dtype == WQ_F8_FNUZ || p->a_dtype == WQ_F8_E4M3FN;
     if(is_f8 && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
-       p->b_dtype == WQ_I4_PACKED && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->M % 256 == 0 && p->N % 256 == 0 &&
+       p->b_dtype == WQ_I4_PACKED && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->M > 64 && p->N % 256 == 0 &&
        plan.k_begin % 128 == 0 && plan.k_per_z % 128 == 0 && (plan.k_end - plan.k_begin) % 128 == 0 &&
        p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
        (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)

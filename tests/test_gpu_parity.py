@@ -368,7 +368,7 @@ def _f8_bytes(rng, shape, exclude=(0x7F, 0xFF, 0x80)):
     return allowed[rng.integers(0, allowed.size, shape)]
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (256, 512, 384), (512, 256, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (256, 512, 384), (512, 256, 1024), (300, 256, 512), (100, 256, 256)])
 def test_f8_mfma_fnuz_vs_checker(port, M, N, K):
     """fp8 FNUZ bytes x packed int4 on the fp8 matrix core (caller excludes 0x7F/0xFF/0x80), MultiplyMultiply
     [+ FastGelu], against the CPU checker and the generic kernel."""
