@@ -250,7 +250,7 @@ def test_bf16_int8_mfma(port):
 def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None, bias=None, relu=False):
     a_t, b_t = dev(a), dev(b)
     ldc = ldc or N
-    e_t = torch.full((M, ldc), 77, dtype=torch.int8, device="cuda")
+    e_t = torch.full((M + 16, ldc), 77, dtype=torch.int8, device="cuda")  # 16 guard rows
     bias_t = dev(np.ascontiguousarray(bias, np.int32)) if bias is not None else None
     epi = ((capi.EPI_ADD_RELU_MUL_CLAMP if relu else capi.EPI_ADD_ACT_MUL_CLAMP) if bias is not None
            else (capi.EPI_RELU_MUL_CLAMP if relu else capi.EPI_ACT_MUL_CLAMP))
@@ -261,7 +261,9 @@ def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None, bias=
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    return e_t.cpu().numpy(), capi.kernel_name(p)
+    e = e_t.cpu().numpy()
+    assert (e[M:] == 77).all(), "rows past M were written"
+    return e[:M], capi.kernel_name(p)
 
 
 def test_c1_int8_requant_gemm_exact(golden_gemm, port):
@@ -338,6 +340,13 @@ def test_int8_bias_relu_requant(golden_gemm, port):
         ref = port.gemm_i8_bias_requant(np.ascontiguousarray(a[:64]), b, bias, 64, N, K, K, K, N, rq, 1).reshape(64, N)
         np.testing.assert_array_equal(e[:64], ref)
     assert ref.min() == 0 and np.unique(ref).size > 20
+    # ragged M stays on the matrix core: partial last row tile, guard rows after E untouched
+    for Mr in (1, 100, 333):
+        ar = np.ascontiguousarray(a[:Mr])
+        e, name = _run_i8(ar, b, Mr, N, K, 2e-4, bias=bias, relu=True)
+        assert name == "wq_gemm_i8_mfma_128"
+        ref = port.gemm_i8_bias_requant(ar, b, bias, Mr, N, K, K, K, N, 2e-4, 1).reshape(Mr, N)
+        np.testing.assert_array_equal(e, ref)
     # a missing bias pointer is a malformed problem
     p = capi.fpAintB_problem(1, 1, None, 1, 128, 128, 128, a_dtype=capi.I8, b_dtype=capi.I8, c_dtype=capi.I8,
                              epilogue=capi.EPI_ADD_RELU_MUL_CLAMP, requant=0.03)
