@@ -36,7 +36,15 @@ def test_is_supported_and_routes():
     assert capi.kernel_name(_problem(flags=capi.FLAG_TILE_128)) == "wq_gemm_mfma_128"
     assert capi.kernel_name(_problem(M=512, N=512)) == "wq_gemm_mfma_128"   # too few 256-tiles to fill the chip
     assert capi.kernel_name(_problem(M=512, N=512, flags=capi.FLAG_TILE_256)) == "wq_gemm_mfma_256"
-    assert not capi.is_supported(_problem(M=384, N=512, flags=capi.FLAG_TILE_256))
+    assert not capi.is_supported(_problem(M=512, N=384, flags=capi.FLAG_TILE_256))   # N must be whole 256-tiles
+    # M need not be: the last row tile of the tile kernels may be partial; up to 64 rows go to the small-M kernel
+    assert capi.kernel_name(_problem(M=384, N=512, flags=capi.FLAG_TILE_256)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(M=4000)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(M=100)) == "wq_gemm_mfma_128"
+    p = _problem(M=100)
+    assert capi.workspace_bytes(p) > 0 and "KBatch" in capi.type_string(p)   # short grid: planner-chosen split-K
+    assert capi.kernel_name(_problem(M=33)) == "wq_gemm_skinny"
+    assert capi.kernel_name(_problem(M=2)) == "wq_gemm_skinny_ws"
     assert not capi.is_supported(_problem(flags=1 << 20))   # unknown flag bits are rejected
     # ragged shapes fall back to the generic HIP kernel (still supported)
     p = _problem(M=33, N=17, K=72, lda=80, ldb=88, ldc=24)
