@@ -567,6 +567,152 @@ def test_full_size_c2_properties(port):
     np.testing.assert_array_equal(bits_to_f32(got2, capi.F16), 2 * bits_to_f32(got, capi.F16))
 
 
+def _launch(p, ws=None):
+    capi.launch(p, ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
+def test_full_size_c3_properties(port):
+    """BASELINE config 3 at full size (bf16 x int8, M = 4096, N = 11008, K = 4096): a row block against the CPU
+    checker, exact agreement of the 256- and 128-tile kernels on integer inputs, exact linearity in the scale."""
+    M, N, K = 4096, 11008, 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    b = torch.randint(-128, 128, (N, K), generator=g, device="cuda", dtype=torch.int8)
+    c = torch.empty((M, N), dtype=torch.int16, device="cuda")
+
+    def run(a, s, flags=0, expect=MFMA256):
+        p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K, a_dtype=capi.BF16,
+                                 b_dtype=capi.I8, flags=flags)
+        assert capi.kernel_name(p) == expect
+        _launch(p)
+        return c.clone()
+
+    a = (torch.rand((M, K), generator=g, device="cuda") * 2 - 1).bfloat16()
+    s = (torch.rand((N,), generator=g, device="cuda") * (2.0 ** -6 - 2.0 ** -10) + 2.0 ** -10).bfloat16()
+    got = run(a, s)
+    rows = slice(3000, 3016)
+    a_h = a[rows].view(torch.int16).cpu().numpy().view(np.uint16)
+    s_h = s.view(torch.int16).cpu().numpy().view(np.uint16)
+    exp = port.gemm_bf16_i8(np.ascontiguousarray(a_h), b.cpu().numpy(), s_h, 16, N, K, K, 1, K, N, 0).reshape(16, N)
+    check_err(bits_to_f32(got[rows].cpu().numpy().view(np.uint16), capi.BF16), bits_to_f32(exp, capi.BF16), 1e-2, 1e-2)
+    # integer inputs: both tile kernels and the checker agree bit for bit
+    ai = torch.randint(-1, 2, (M, K), generator=g, device="cuda").bfloat16()
+    si = torch.randint(1, 3, (N,), generator=g, device="cuda").bfloat16()
+    g256 = run(ai, si)
+    g128 = run(ai, si, flags=capi.FLAG_TILE_128, expect=MFMA)
+    assert torch.equal(g256, g128)
+    exp = port.gemm_bf16_i8(np.ascontiguousarray(ai[rows].view(torch.int16).cpu().numpy().view(np.uint16)), b.cpu().numpy(),
+                            si.view(torch.int16).cpu().numpy().view(np.uint16), 16, N, K, K, 1, K, N, 0).reshape(16, N)
+    np.testing.assert_array_equal(g256[rows].cpu().numpy().view(np.uint16), exp)
+    # doubling every scale doubles every output exactly
+    g2 = run(ai, (si.float() * 2).bfloat16())
+    assert torch.equal(g2.view(torch.bfloat16).float(), 2 * g256.view(torch.bfloat16).float())
+
+
+def test_full_size_c4_slices_properties(port):
+    """BASELINE config 4 on one GPU (fp16 x int4, M = N = 4096, K = 65536 in 8 slices of 8192): on integer inputs the sum
+    of the eight fp32 slice partials + finalize equals the single-pass kernel over the whole K bit for bit; a row block
+    of a slice partial equals the checker's partial; realistic inputs stay within the K-scaled tolerance."""
+    M = N = 4096
+    K, G = 65536, 8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    q = torch.randint(-8, 8, (N, K), generator=g, device="cuda", dtype=torch.int8)
+    bp = torch.empty((N, K // 2), dtype=torch.uint8, device="cuda")
+    capi.pack_int4(q.data_ptr(), K, K, N, bp.data_ptr(), K // 2, torch.cuda.current_stream().cuda_stream)
+    ai = torch.randint(-1, 2, (M, K), generator=g, device="cuda").half()
+    si = torch.randint(1, 3, (N,), generator=g, device="cuda").half()
+    kread = capi.splitk_kread(K, G)
+    assert kread == 8192
+    total = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    part = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    first = None
+    for gi in range(G):
+        p = capi.fpAintB_problem(ai.data_ptr(), bp.data_ptr(), si.data_ptr(), part.data_ptr(), M, N, K,
+                                 k_begin=gi * kread, k_end=(gi + 1) * kread, c_dtype=capi.F32)
+        assert capi.kernel_name(p) == MFMA256
+        _launch(p)
+        total += part
+        if gi == 0:
+            first = part[:8].cpu().numpy()
+    exp = port.fpAintB_partial(ai[:8].cpu().numpy().view(np.uint16), q.cpu().numpy(), si.cpu().numpy().view(np.uint16), 8, N, K,
+                               K, 0, kread)
+    np.testing.assert_array_equal(first, exp.reshape(8, N))
+    c_sum = torch.empty((M, N), dtype=torch.int16, device="cuda")
+    c_one = torch.empty((M, N), dtype=torch.int16, device="cuda")
+    p = capi.fpAintB_problem(ai.data_ptr(), bp.data_ptr(), si.data_ptr(), c_sum.data_ptr(), M, N, K)
+    capi.reduce_finalize(p, total.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+    p1 = capi.fpAintB_problem(ai.data_ptr(), bp.data_ptr(), si.data_ptr(), c_one.data_ptr(), M, N, K)
+    assert capi.kernel_name(p1) == MFMA256
+    _launch(p1)
+    assert torch.equal(c_sum, c_one)
+    # realistic inputs: slices + sum against the single pass; the fp32 summation order differs, so the tolerance of
+    # check_err's half defaults is widened by sqrt(K / 4096)
+    a = (torch.rand((M, K), generator=g, device="cuda") * 2 - 1).half()
+    s = (torch.rand((N,), generator=g, device="cuda") * (2.0 ** -4 - 2.0 ** -8) + 2.0 ** -8).half()
+    total.zero_()
+    for gi in range(G):
+        p = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), s.data_ptr(), part.data_ptr(), M, N, K,
+                                 k_begin=gi * kread, k_end=(gi + 1) * kread, c_dtype=capi.F32)
+        _launch(p)
+        total += part
+    p = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), s.data_ptr(), c_sum.data_ptr(), M, N, K)
+    capi.reduce_finalize(p, total.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+    p1 = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), s.data_ptr(), c_one.data_ptr(), M, N, K)
+    _launch(p1)
+    tol = 1e-3 * (K / 4096) ** 0.5
+    check_err(c_sum.view(torch.float16).float().cpu().numpy(), c_one.view(torch.float16).float().cpu().numpy(), tol, tol)
+    exp = port.fpAintB_gemm_f16(a[:4].cpu().numpy().view(np.uint16), q.cpu().numpy(), s.cpu().numpy().view(np.uint16), 4, N, K,
+                                K, K, N).reshape(4, N)
+    check_err(c_one[:4].view(torch.float16).float().cpu().numpy(), bits_to_f32(exp, capi.F16), tol, tol)
+
+
+def test_full_size_c5_properties(port):
+    """BASELINE config 5 at full size (fp8 x int4 + MultiplyMultiply [+ FastGelu], 4096^3 and example/65's default
+    3840 x 4096 x 4096): a row block against the CPU checker, exactness on the exact input set, and exact doubling of
+    the output when the per-row factors double."""
+    for M in (4096, 3840):
+        N = K = 4096
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5 + M)
+        q = torch.randint(-8, 8, (N, K), generator=g, device="cuda", dtype=torch.int8)
+        bp = torch.empty((N, K // 2), dtype=torch.uint8, device="cuda")
+        capi.pack_int4(q.data_ptr(), K, K, N, bp.data_ptr(), K // 2, torch.cuda.current_stream().cuda_stream)
+        a = (torch.rand((M, K), generator=g, device="cuda") * 2 - 1).to(torch.float8_e4m3fnuz).view(torch.uint8)
+        a[a == 0x80] = 0
+        d0 = torch.rand((N,), generator=g, device="cuda") * 2.0 ** -3
+        d1 = torch.rand((M,), generator=g, device="cuda")
+        c = torch.empty((M, N), dtype=torch.int16, device="cuda")
+
+        def run(a_, d0_, d1_, kind):
+            p = capi.fpAintB_problem(a_.data_ptr(), bp.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_FNUZ,
+                                     c_dtype=capi.F16, epilogue=kind, d0=d0_.data_ptr(), d1=d1_.data_ptr(),
+                                     flags=capi.FLAG_F8_NO_SPECIALS)
+            assert capi.kernel_name(p) == F8_MFMA
+            _launch(p)
+            return c.clone()
+
+        rows = slice(M - 16, M)
+        q_h = q.cpu().numpy()
+        for gelu, kind in ((False, capi.EPI_MULTIPLY_MULTIPLY), (True, capi.EPI_MULTIPLY_MULTIPLY_FASTGELU)):
+            got = run(a, d0, d1, kind)
+            exp = port.gemm_f8_i8_mm(np.ascontiguousarray(a[rows].cpu().numpy()), q_h, d0.cpu().numpy(),
+                                     np.ascontiguousarray(d1[rows].cpu().numpy()), 16, N, K, K, K, N, gelu).reshape(16, N)
+            check_err(got[rows].view(torch.float16).float().cpu().numpy(), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+        # exact set: activations in {-2 .. 2}, power-of-two factors: bit-exact against the checker
+        lut = torch.tensor([0xC8, 0xC0, 0x00, 0x40, 0x48], dtype=torch.uint8, device="cuda")
+        ae = lut[torch.randint(0, 5, (M, K), generator=g, device="cuda")]
+        d0e = torch.pow(2.0, torch.randint(-3, 1, (N,), generator=g, device="cuda").float())
+        d1e = torch.pow(2.0, torch.randint(-3, 1, (M,), generator=g, device="cuda").float())
+        got = run(ae, d0e, d1e, capi.EPI_MULTIPLY_MULTIPLY)
+        exp = port.gemm_f8_i8_mm(np.ascontiguousarray(ae[rows].cpu().numpy()), q_h, d0e.cpu().numpy(),
+                                 np.ascontiguousarray(d1e[rows].cpu().numpy()), 16, N, K, K, K, N, False).reshape(16, N)
+        np.testing.assert_array_equal(got[rows].cpu().numpy().view(np.uint16), exp)
+        got2 = run(ae, d0e, 2 * d1e, capi.EPI_MULTIPLY_MULTIPLY)
+        assert torch.equal(got2.view(torch.float16).float(), 2 * got.view(torch.float16).float())
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 256, 1024), (768, 1024, 4096)])
 def test_tile256_kernel_fp16_int4(port, M, N, K):
     """The 256 x 256 kernel (3-buffer LDS ring, counted waits) forced at small and ragged tile counts:
