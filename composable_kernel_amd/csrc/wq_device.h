@@ -168,16 +168,19 @@ __device__ __forceinline__ u4_t dequant8_bytes_bf16(const ScaleReg<A_BF16>& sc, 
         w[0] ^= 0x80808080u;
         w[1] ^= 0x80808080u;
     }
+    // two products per v_pk_fma_f32
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t s2 = {sc.s, sc.s}, m2 = {sc.m128s, sc.m128s};
     u4_t r;
 #pragma unroll
     for(int d = 0; d < 2; ++d)
     {
-        const float p0 = __builtin_fmaf(u8_to_f32(w[d], 0), sc.s, sc.m128s);
-        const float p1 = __builtin_fmaf(u8_to_f32(w[d], 1), sc.s, sc.m128s);
-        const float p2 = __builtin_fmaf(u8_to_f32(w[d], 2), sc.s, sc.m128s);
-        const float p3 = __builtin_fmaf(u8_to_f32(w[d], 3), sc.s, sc.m128s);
-        r[2 * d]     = __builtin_amdgcn_perm(as_u32(p1), as_u32(p0), 0x07060302u);
-        r[2 * d + 1] = __builtin_amdgcn_perm(as_u32(p3), as_u32(p2), 0x07060302u);
+        const f2_t u01 = {u8_to_f32(w[d], 0), u8_to_f32(w[d], 1)};
+        const f2_t u23 = {u8_to_f32(w[d], 2), u8_to_f32(w[d], 3)};
+        const f2_t p01 = __builtin_elementwise_fma(u01, s2, m2);
+        const f2_t p23 = __builtin_elementwise_fma(u23, s2, m2);
+        r[2 * d]     = __builtin_amdgcn_perm(as_u32(p01[1]), as_u32(p01[0]), 0x07060302u);
+        r[2 * d + 1] = __builtin_amdgcn_perm(as_u32(p23[1]), as_u32(p23[0]), 0x07060302u);
     }
     return r;
 }
@@ -186,14 +189,16 @@ __device__ __forceinline__ u4_t dequant8_bytes_bf16(const ScaleReg<A_BF16>& sc, 
 __device__ __forceinline__ u4_t dequant8(const ScaleReg<A_BF16>& sc, uint32_t w,
                                          std::integral_constant<int, B_I4P>)
 {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
     const float m8s = sc.m128s * 0.0625f; // -8 s, exact
+    const f2_t s2 = {sc.s, sc.s}, m2 = {m8s, m8s};
     u4_t r;
 #pragma unroll
     for(int i = 0; i < 4; ++i)
     {
-        const float lo = __builtin_fmaf((float)((w >> (4 * i)) & 0xFu), sc.s, m8s);
-        const float hi = __builtin_fmaf((float)((w >> (4 * i + 16)) & 0xFu), sc.s, m8s);
-        r[i]           = __builtin_amdgcn_perm(as_u32(hi), as_u32(lo), 0x07060302u);
+        const f2_t n = {(float)((w >> (4 * i)) & 0xFu), (float)((w >> (4 * i + 16)) & 0xFu)};
+        const f2_t v = __builtin_elementwise_fma(n, s2, m2); // one v_pk_fma_f32 for the pair
+        r[i]         = __builtin_amdgcn_perm(as_u32(v[1]), as_u32(v[0]), 0x07060302u);
     }
     return r;
 }
