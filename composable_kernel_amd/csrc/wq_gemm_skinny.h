@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 // Variant for M <= 16 that needs neither split-K workspace nor a reduce kernel: the four waves of a workgroup
 // own the SAME 16 columns and a quarter of K each; their accumulators are summed through LDS and wave 0 applies
 // the epilogue.  grid (N / 16), 256 threads.  Only the M real rows of the activations are staged (lanes of the
-// zero rows read nothing), so M = 1 costs 2 K bytes of LDS.  Super-steps per wave must be a multiple of P.
+// zero rows read nothing), so M = 1 costs 2 K bytes of LDS; the image must fit (the planner uses this variant up to
+// 40 KiB).  Super-steps per wave must be a multiple of P.
 template <int AK, int BKIND, int P>
 __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 {
@@ -293,6 +294,158 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
     }
 
     // sum the four K quarters in ascending order through LDS (the activation image is no longer needed)
+    __syncthreads();
+    f4_t* red = (f4_t*)lds;
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if(wave == 0 && live)
+    {
+        f4_t v = red[lane];
+#pragma unroll
+        for(int w = 1; w < 4; ++w)
+        {
+            const f4_t u = red[w * 64 + lane];
+            v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+        }
+        const int m = fr, n = n0 + fq * 4;
+        uint16_t o[4];
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+            o[j] = cvt_out16(apply_epilogue(p.epi, v[j], m, n + j), p.epi.c_dtype);
+        u2_t pk;
+        pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *(u2_t*)((uint16_t*)p.c + (size_t)m * p.ldc + n) = pk;
+    }
+}
+
+// The same division of work for activation images too large to stage whole (M up to 16 at any K): each wave passes
+// the activations of its own K quarter through a
+// private LDS region chunk by chunk (next chunk prefetched into registers; only the M real rows are moved, and
+// lanes of the zero rows read nothing), so there is no barrier in the loop and the footprint is 9 - 33 KiB whatever
+// K and M are.  Super-steps per wave must be a multiple of P.
+template <int AK, int BKIND, int P>
+__global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
+{
+    constexpr int CH     = BKIND == B_I4P ? 32 : 16;
+    constexpr int KS     = 4 * CH;
+    constexpr int STEPS  = CH / 8;
+    constexpr int SPC    = P >= 2 ? 2 : 1;       // super-steps per activation chunk
+    constexpr int KC     = SPC * KS;
+    constexpr int PITCH  = KC * 2 + 16;
+    constexpr int CPR    = KC / 8;               // 16-byte pieces per row of a chunk
+    constexpr int APT    = 16 * CPR / 64;        // pieces per lane (16 rows)
+    constexpr int REGION = 16 * PITCH;
+    static_assert(16 * CPR % 64 == 0 && 4 * REGION >= 4 * 64 * 16);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * REGION];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr   = lane & 15;
+    const int fq   = lane >> 4;
+    const int n0   = blockIdx.x * 16;
+
+    const int klen    = p.k_end - p.k_begin;
+    const int kw      = klen / 4;            // K range of one wave
+    const int nsteps  = kw / KS;             // a multiple of P (host-checked), >= P
+    const int nchunks = nsteps / SPC;
+    const int kbeg    = p.k_begin + wave * kw;
+
+    const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
+                          (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
+    u4_t raw[P];
+#pragma unroll
+    for(int i = 0; i < P; ++i)
+        raw[i] = *(const u4_t*)(bptr + (size_t)i * 64);
+
+    // activation chunks of this wave: piece q = lane + 64 j is 16 bytes of row q / CPR
+    uint8_t* my = lds + wave * REGION;
+    const uint8_t* a_src[APT];
+    int a_dst[APT];
+    bool a_ok[APT];
+#pragma unroll
+    for(int j = 0; j < APT; ++j)
+    {
+        const int q   = lane + 64 * j;
+        const int row = q / CPR, ch = q - row * CPR;
+        a_ok[j]       = row < p.M;
+        a_src[j]      = (const uint8_t*)p.a + ((size_t)(a_ok[j] ? row : 0) * p.lda + kbeg) * 2 + ch * 16;
+        a_dst[j]      = row * PITCH + ch * 16;
+    }
+    u4_t apre[APT];
+    auto fetch_chunk = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for(int j = 0; j < APT; ++j)
+            if(a_ok[j])
+                apre[j] = *(const u4_t*)(a_src[j] + (size_t)c * KC * 2);
+    };
+    fetch_chunk(0);
+
+    ScaleReg<AK> sc;
+    sc.set(p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>());
+
+    f4_t acc            = {0.f, 0.f, 0.f, 0.f};
+    const bool live     = fr < p.M; // this lane's activation row exists
+    const uint8_t* a_ln = my + (live ? fr : 0) * PITCH + fq * CH * 2;
+    for(int t = 0; t < nsteps; t += P)
+    {
+#pragma unroll
+        for(int cc = 0; cc < P / SPC; ++cc)
+        {
+            const int c = t / SPC + cc;
+            // the fragment reads of the previous chunk have been consumed by its MFMAs; LDS serves one wave's
+            // accesses in order, the wait publishes the writes to the wave's other lanes before they are read
+#pragma unroll
+            for(int j = 0; j < APT; ++j)
+                if(a_ok[j])
+                    *(u4_t*)(my + a_dst[j]) = apre[j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            fetch_chunk(min(c + 1, nchunks - 1));
+#pragma unroll
+            for(int ii = 0; ii < SPC; ++ii)
+            {
+                const int i   = cc * SPC + ii;
+                const u4_t w  = raw[i];
+                const int nxt = min(t + i + P, nsteps - 1);
+                raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * 64);
+                u4_t af[STEPS];
+#pragma unroll
+                for(int s = 0; s < STEPS; ++s)
+                {
+                    af[s] = *(const u4_t*)(a_ln + (ii * KS + 8 * s) * 2);
+                    if(!live)
+                        af[s] = u4_t{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for(int s = 0; s < STEPS; ++s)
+                {
+                    u4_t wf;
+                    if constexpr(BKIND == B_I4P)
+                        wf = dequant8(sc, w[s], std::integral_constant<int, B_I4P>{});
+                    else
+                    {
+                        const u2_t w8 = {w[2 * s], w[2 * s + 1]};
+                        if constexpr(AK == A_F16)
+                            wf = dequant8_bytes_f16<BKIND>(sc, w8);
+                        else
+                            wf = dequant8_bytes_bf16<BKIND>(sc, w8);
+                    }
+                    if constexpr(AK == A_F16)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wf), __builtin_bit_cast(h8_t, af[s]),
+                                                                     acc, 0, 0, 0);
+                    else
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, wf),
+                                                                      __builtin_bit_cast(bf8_t, af[s]), acc, 0, 0, 0);
+                }
+            }
+            // all fragment reads of this chunk are complete before the next chunk overwrites the region
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // sum the four K quarters in ascending order through LDS (the activation images are no longer needed)
     __syncthreads();
     f4_t* red = (f4_t*)lds;
     red[wave * 64 + lane] = acc;

@@ -28,18 +28,10 @@ int launch_ab(const GemmParams& gp, dim3 grid, hipStream_t s, int nmb, int p)
 template <int AK, int BKIND, int P>
 int launch_ws_t(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
 {
-    static bool opted_in[64] = {};
-    int dev                  = 0;
-    if(hipGetDevice(&dev) != hipSuccess)
-        return WQ_ERR_HIP;
-    if(dev >= 0 && dev < 64 && !opted_in[dev])
-    {
-        if(hipFuncSetAttribute((const void*)wq_gemm_skinny_ws<AK, BKIND, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               144 * 1024) != hipSuccess)
-            return WQ_ERR_HIP;
-        opted_in[dev] = true;
-    }
-    hipLaunchKernelGGL((wq_gemm_skinny_ws<AK, BKIND, P>), grid, dim3(256), lds_bytes, s, gp);
+    if(lds_bytes > 0) // whole activation image in (dynamic) LDS
+        hipLaunchKernelGGL((wq_gemm_skinny_ws<AK, BKIND, P>), grid, dim3(256), lds_bytes, s, gp);
+    else // chunked, per-wave regions (static LDS)
+        hipLaunchKernelGGL((wq_gemm_skinny_wsc<AK, BKIND, P>), grid, dim3(256), 0, s, gp);
     return WQ_OK;
 }
 
@@ -53,7 +45,8 @@ int launch_ws_ab(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, 
 
 } // namespace
 
-// waves-split-K variant (M <= 16): p = loads in flight, super-steps per wave % p == 0
+// waves-split-K variants (M <= 16): p = loads in flight, super-steps per wave % p == 0; lds_bytes > 0 selects the
+// whole-image kernel (at most 40 KiB, below the 64 KiB that need no opt-in), 0 the chunked one
 int launch_skinny_ws(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int p)
 {
     if(ak == A_F16)

@@ -208,11 +208,12 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                               klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
                               p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 &&
                               (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0;
-        // M <= 16 with the whole K range of the real rows in LDS: four waves split K inside the workgroup, one
-        // kernel, no workspace
+        // M <= 16: four waves split K inside the workgroup, one kernel, no workspace -- as long as N / 16 workgroups
+        // occupy the chip and K is short enough that splitting it across the grid would not pay for a second kernel
+        // (every workgroup reads all M rows of the activations: N / 16 * M * K * 2 bytes from L2 in total, four times
+        // what the grid-split kernel reads; measured break-even near 96 MB)
         if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all % (4 * ks) == 0 && p->N % 16 == 0 &&
-           (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024 && p->N / 16 >= 128 && // (larger images cost more than the reduce kernel saves)
-           klen_all <= 8192) // (a longer K on N / 16 workgroups is better split across the grid)
+           p->N / 16 >= 128 && klen_all <= 8192 && (long)(p->N / 16) * p->M * klen_all * 2 <= 96L * 1000 * 1000)
         {
             plan.route = ROUTE_SKINNY_WS;
             return WQ_OK;
@@ -477,8 +478,11 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.epi     = epilogue_of(p);
         const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, klen = plan.k_end - plan.k_begin;
         const int steps_per_wave = klen / 4 / ks;
-        int lds_bytes            = p->M * (klen * 2 + 16);
-        if(lds_bytes < 4096)
+        // the whole activation image in LDS when it is small (no synchronisation in the loop), else chunk by chunk
+        int lds_bytes = p->M * (klen * 2 + 16);
+        if(lds_bytes > 40 * 1024)
+            lds_bytes = 0;
+        else if(lds_bytes < 4096)
             lds_bytes = 4096; // the cross-wave sum needs 4 x 64 x 16 bytes
         const int rc = wq::launch_skinny_ws(plan.ak, plan.bk, gp, dim3(p->N / 16), lds_bytes, s,
                                             steps_per_wave % 4 == 0 ? 4 : (steps_per_wave % 2 == 0 ? 2 : 1));
@@ -718,7 +722,8 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"
              : plan.route == ROUTE_SKINNY ? "wq_gemm_skinny"
-             : plan.route == ROUTE_SKINNY_WS ? "wq_gemm_skinny_ws"
+             : plan.route == ROUTE_SKINNY_WS
+                 ? ((size_t)p->M * ((plan.k_end - plan.k_begin) * 2 + 16) <= 40 * 1024 ? "wq_gemm_skinny_ws" : "wq_gemm_skinny_wsc")
              : plan.route == ROUTE_MFMA128 ? "wq_gemm_mfma_128"
                                            : "wq_gemm_generic");
     return WQ_OK;

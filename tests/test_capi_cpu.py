@@ -45,6 +45,7 @@ def test_is_supported_and_routes():
     assert capi.workspace_bytes(p) > 0 and "KBatch" in capi.type_string(p)   # short grid: planner-chosen split-K
     assert capi.kernel_name(_problem(M=33)) == "wq_gemm_skinny"
     assert capi.kernel_name(_problem(M=2)) == "wq_gemm_skinny_ws"
+    assert capi.kernel_name(_problem(M=16)) == "wq_gemm_skinny_wsc"
     assert not capi.is_supported(_problem(flags=1 << 20))   # unknown flag bits are rejected
     # ragged shapes fall back to the generic HIP kernel (still supported)
     p = _problem(M=33, N=17, K=72, lda=80, ldb=88, ldc=24)

@@ -979,8 +979,9 @@ def test_small_m_kernel_long_k(port, M, K, a_dtype, b_dtype):
     check_err(bits_to_f32(got, a_dtype), bits_to_f32(ref(a, s), a_dtype), tol, 1e-3 * max(1.0, (K / 4096) ** 0.5))
 
 
-@pytest.mark.parametrize("M", [1, 3, 16])
+@pytest.mark.parametrize("M", [1, 3, 9, 16])
 @pytest.mark.parametrize("a_dtype,b_dtype,K", [(capi.F16, capi.I4_PACKED, 1024), (capi.F16, capi.I4_PACKED, 1536),
+                                               (capi.F16, capi.I4_PACKED, 4096), (capi.BF16, capi.I8, 2048),
                                                (capi.BF16, capi.I8, 1024), (capi.BF16, capi.I4_PACKED, 512),
                                                (capi.F16, capi.U8_OFFSET, 768)])
 def test_small_m_kernel_waves_split_k(port, M, a_dtype, b_dtype, K):
@@ -1003,8 +1004,8 @@ def test_small_m_kernel_waves_split_k(port, M, a_dtype, b_dtype, K):
             return port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
         return port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
 
-    # (the activation image must stay below 40 KiB of LDS for this variant)
-    name = "wq_gemm_skinny_ws" if M * (2 * K + 16) <= 40 * 1024 else SKINNY
+    # the whole activation image in LDS up to 40 KiB, chunk by chunk through per-wave regions beyond
+    name = "wq_gemm_skinny_ws" if M * (2 * K + 16) <= 40 * 1024 else "wq_gemm_skinny_wsc"
     a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
     s = cvt(rng.integers(1, 3, N).astype(np.float32))
     got = run_fpaintb(a, b, s, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, expect_kernel=name)
