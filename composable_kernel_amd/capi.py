@@ -16,7 +16,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libwqgemm.so")
+# WQGEMM_LIB names another build of the same library (A/B timing of two builds in one session)
+LIB_PATH = os.environ.get("WQGEMM_LIB") or os.path.join(HERE, "csrc", "libwqgemm.so")
 
 # wq_status
 OK, ERR_UNSUPPORTED, ERR_INVALID, ERR_HIP, ERR_WORKSPACE = range(5)

@@ -139,35 +139,46 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
                                                        int m0, int n0, int row_w, int col_w, int fr, int fq,
                                                        int wave, int lane)
 {
-#pragma unroll
-    for(int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for(int mt = 0; mt < MT; ++mt)
-        {
-            const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
-            const int m = min(m0 + r, p.M - 1); // rows of a partial last tile past M: keep per-row operand reads in range
-            uint16_t o[4];
-#pragma unroll
-            for(int j = 0; j < 4; ++j)
-            {
-                const float y = apply_epilogue_k<KIND>(p.epi, acc[nt][mt][j], m, n0 + c + j);
-                o[j]          = BF16 ? f32_to_bf16_trunc(y) : __builtin_bit_cast(uint16_t, (_Float16)y);
-            }
-            u2_t pk;
-            pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-            pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-            *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
-        }
-    __syncthreads();
+    // When every wave's fragments span all 256 rows (1 x 8 wave grid) the tile goes out in two halves: the stores
+    // of rows 0 .. 127 drain while the epilogue arithmetic of rows 128 .. 255 runs.
+    constexpr int PHASES = MT * RSTEP == 256 ? 2 : 1;
+    constexpr int MTP    = MT / PHASES;
     uint16_t* cg = (uint16_t*)p.c + (size_t)m0 * p.ldc + n0;
-#pragma unroll 4
-    for(int i = 0; i < 16; ++i)
+#pragma unroll
+    for(int ph = 0; ph < PHASES; ++ph)
     {
-        const int r   = wave * 32 + 2 * i + (lane >> 5);
-        const int c16 = lane & 31;
-        const u4_t v  = *(const u4_t*)(lds + r * kCTilePitch + c16 * 16);
-        if(m0 + r < p.M) // the last row tile may be partial
-            *(u4_t*)(cg + (size_t)r * p.ldc + c16 * 8) = v;
+#pragma unroll
+        for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for(int mi = 0; mi < MTP; ++mi)
+            {
+                const int mt = ph * MTP + mi;
+                const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
+                const int m = min(m0 + r, p.M - 1); // rows of a partial last tile past M: keep per-row operand reads in range
+                uint16_t o[4];
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+                {
+                    const float y = apply_epilogue_k<KIND>(p.epi, acc[nt][mt][j], m, n0 + c + j);
+                    o[j]          = BF16 ? f32_to_bf16_trunc(y) : __builtin_bit_cast(uint16_t, (_Float16)y);
+                }
+                u2_t pk;
+                pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+                pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
+            }
+        __syncthreads();
+        constexpr int ROWS_PH = 256 / PHASES;     // rows streamed out in this phase
+        constexpr int ITERS   = ROWS_PH / 16;     // 8 waves x 2 rows per wave-instruction
+#pragma unroll 4
+        for(int i = 0; i < ITERS; ++i)
+        {
+            const int r   = ph * ROWS_PH + wave * (ROWS_PH / 8) + 2 * i + (lane >> 5);
+            const int c16 = lane & 31;
+            const u4_t v  = *(const u4_t*)(lds + r * kCTilePitch + c16 * 16);
+            if(m0 + r < p.M) // the last row tile may be partial
+                *(u4_t*)(cg + (size_t)r * p.ldc + c16 * 8) = v;
+        }
     }
 }
 
