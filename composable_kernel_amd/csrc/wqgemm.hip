@@ -297,10 +297,12 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     {
         const int wgs  = ((p->M + 127) / 128) * (p->N / 128);
         const int klen = plan.k_end - plan.k_begin;
-        int kb         = 256 / wgs;
+        // (up to 128 workgroups: about one per CU after the split; up to two per CU, which the 128-tile kernel runs
+        // side by side, halves of a long K still pay: measured 15 - 20 % at 4096 <= K)
+        int kb         = wgs <= 128 ? 256 / wgs : (wgs < 512 && klen >= 4096 ? 2 : 1);
         if(kb > klen / 256)
             kb = klen / 256;
-        if(wgs <= 128 && kb > 1)
+        if(kb > 1)
         {
             const int per = wqgemm_splitk_kread(klen, kb, 64);
             kb            = (klen + per - 1) / per;
