@@ -549,6 +549,7 @@ __device__ __forceinline__ float f8_e4m3fn_to_f32(uint8_t x)
 __global__ __launch_bounds__(256) void wq_transpose_b8(const uint8_t* b, int ldb, int K, int N, uint8_t* out)
 {
     __shared__ uint8_t tile[64][64 + 4];
+    (void)N; // the grid (N / 64, K / 64) carries the extent
     const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int t  = threadIdx.x;
     // read: thread t -> row k = t / 4 (+0), 16 bytes at n = 16 (t % 4)
