@@ -503,6 +503,120 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
 }
 
 
+// The same GEMM on 256 x 256 x 128 tiles for problems that fill the chip: 8 waves in a 2 x 4 grid (each 128 rows x 64
+// columns = 8 x 4 accumulator fragments), both operands by LDS-DMA into a two-stage ring (2 x 64 KiB), 24 fragment
+// reads for 64 MFMAs per K tile and wave (the 128-tile kernel: 16 for 32), and the requantised int8 tile staged
+// through LDS so that it leaves as whole 256-byte rows.  Any M >= 1 (partial last row tile).
+constexpr int kI8Tile256Lds = 4 * 256 * 128;
+
+__global__ __launch_bounds__(512) void wq_gemm_i8_mfma_256(const I8GemmParams p)
+{
+    constexpr int TILE = 256 * 128; // bytes of one operand tile
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int ntiles = p.K / 128;
+
+    const uint8_t *a_src[4], *b_src[4];
+#pragma unroll
+    for(int i = 0; i < 4; ++i)
+    {
+        const int row   = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        a_src[i]        = (const uint8_t*)p.a + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk * 16;
+        b_src[i]        = (const uint8_t*)p.b + (size_t)(n0 + row) * p.ldb + chunk * 16;
+    }
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
+        uint8_t* sa = lds + buf * 2 * TILE;
+        uint8_t* sb = sa + TILE;
+#pragma unroll
+        for(int i = 0; i < 4; ++i)
+        {
+            glds16(a_src[i] + (size_t)kt * 128, sa + (wave * 4 + i) * 1024);
+            glds16(b_src[i] + (size_t)kt * 128, sb + (wave * 4 + i) * 1024);
+        }
+    };
+
+    i4_t acc[4][8]; // [nt][mt]
+#pragma unroll
+    for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < 8; ++mt)
+            acc[nt][mt] = i4_t{0, 0, 0, 0};
+
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const uint8_t* sa = lds + buf * 2 * TILE;
+        const uint8_t* sb = sa + TILE;
+#pragma unroll
+        for(int s = 0; s < 2; ++s) // two 64-deep MFMA steps per tile
+        {
+            i4_t wf[4], af[8];
+#pragma unroll
+            for(int t = 0; t < 4; ++t)
+            {
+                const int nrow = wn * 64 + t * 16 + fr;
+                wf[t]          = *(const i4_t*)(sb + nrow * 128 + (((4 * s + fq) ^ (nrow & 7)) << 4));
+            }
+#pragma unroll
+            for(int t = 0; t < 8; ++t)
+            {
+                const int mrow = wm * 128 + t * 16 + fr;
+                af[t]          = *(const i4_t*)(sa + mrow * 128 + (((4 * s + fq) ^ (mrow & 7)) << 4));
+            }
+#pragma unroll
+            for(int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for(int nt = 0; nt < 4; ++nt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    };
+
+    if(ntiles > 0)
+    {
+        stage(0, 0);
+        __syncthreads();
+        for(int t = 0; t < ntiles; ++t)
+        {
+            const int cur = t & 1;
+            if(t + 1 < ntiles)
+                stage(cur ^ 1, t + 1);
+            compute(cur);
+            __syncthreads();
+        }
+    }
+    // requantise into an LDS image of the tile (256 rows x 256 bytes, pitch 272), then stream whole rows out
+    constexpr int PITCH = 256 + 16;
+#pragma unroll
+    for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < 8; ++mt)
+        {
+            const int r = wm * 128 + mt * 16 + fr, c = wn * 64 + nt * 16 + fq * 4;
+            uint32_t pk = 0;
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                pk |= (uint32_t)(uint8_t)requant_epilogue(p.kind, p.requant, acc[nt][mt][j], p.bias, n0 + c + j) << (8 * j);
+            *(uint32_t*)(lds + r * PITCH + c) = pk;
+        }
+    __syncthreads();
+    int8_t* cg = (int8_t*)p.c + (size_t)m0 * p.ldc + n0;
+#pragma unroll
+    for(int i = 0; i < 8; ++i)
+    {
+        const int r   = wave * 32 + 4 * i + (lane >> 4);
+        const int c16 = lane & 15;
+        const u4_t v  = *(const u4_t*)(lds + r * PITCH + c16 * 16);
+        if(m0 + r < p.M)
+            *(u4_t*)(cg + (size_t)r * p.ldc + c16 * 16) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic kernel: any M, N, K slice and strides; one thread per output element, fp32 accumulate
 // in ascending k (the reference's own evaluation order).

@@ -53,6 +53,7 @@ enum Route
     ROUTE_MFMA128,
     ROUTE_MFMA256,
     ROUTE_I8_MFMA128,
+    ROUTE_I8_MFMA256,
     ROUTE_F8_MFMA256,
     ROUTE_SKINNY,
     ROUTE_SKINNY_WS,
@@ -140,6 +141,14 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                               p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 &&
                               (uintptr_t)p->c % 4 == 0 && !(p->flags & WQ_FLAG_GENERIC);
         plan.route = tiled_i8 ? ROUTE_I8_MFMA128 : ROUTE_GENERIC;
+        // 256 x 256 tiles once they cover at least half the chip (and on request)
+        if(tiled_i8 && p->N % 256 == 0 && p->ldc % 16 == 0 && (uintptr_t)p->c % 16 == 0 && !(p->flags & WQ_FLAG_TILE_128) &&
+           ((long)((p->M + 255) / 256) * (p->N / 256) >= 128 || (p->flags & WQ_FLAG_TILE_256)))
+            plan.route = ROUTE_I8_MFMA256;
+        if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_I8_MFMA256)
+            return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs N to be a multiple of 256 and tile-aligned operands");
+        if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_I8_MFMA128)
+            return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_128 needs N to be a multiple of 128 and tile-aligned operands");
         return WQ_OK;
     }
 
@@ -491,6 +500,28 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         if(rc != WQ_OK)
             return fail(WQ_ERR_HIP, "small-M kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
+    else if(plan.route == ROUTE_I8_MFMA256)
+    {
+        wq::I8GemmParams gp;
+        gp.a = p->a, gp.b = p->b, gp.c = p->c;
+        gp.M = p->M, gp.N = p->N, gp.K = p->K;
+        gp.lda = p->lda, gp.ldb = p->ldb, gp.ldc = p->ldc;
+        gp.tiles_m = (p->M + 255) / 256, gp.tiles_n = p->N / 256;
+        gp.group_m = gp.tiles_m >= 8 ? 8 : gp.tiles_m;
+        gp.requant = p->requant_scale;
+        gp.kind    = p->epilogue;
+        gp.bias    = (const int32_t*)p->d0;
+        static bool opted_in[64] = {}; // more than 64 KiB of dynamic LDS must be opted into once per device
+        int dev                  = 0;
+        WQ_HIP(hipGetDevice(&dev));
+        if(dev >= 0 && dev < 64 && !opted_in[dev])
+        {
+            WQ_HIP(hipFuncSetAttribute((const void*)wq::wq_gemm_i8_mfma_256, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       wq::kI8Tile256Lds));
+            opted_in[dev] = true;
+        }
+        hipLaunchKernelGGL(wq::wq_gemm_i8_mfma_256, dim3(gp.tiles_m * gp.tiles_n), dim3(512), wq::kI8Tile256Lds, s, gp);
+    }
     else if(plan.route == ROUTE_I8_MFMA128)
     {
         wq::I8GemmParams gp;
@@ -688,6 +719,8 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
     }
     if(plan.route == ROUTE_I8_MFMA128)
         snprintf(buf, n, "DeviceGemmQuantization_Mfma_gfx950<256, 128, 128, 128, 16x16x64, I8, I8, I8, LdsDma>");
+    else if(plan.route == ROUTE_I8_MFMA256)
+        snprintf(buf, n, "DeviceGemmQuantization_Mfma_gfx950<512, 256, 256, 128, 16x16x64, I8, I8, I8, LdsDma>");
     else if(plan.route == ROUTE_F8_MFMA256)
         snprintf(buf, n,
                  "DeviceGemmMultiplyMultiply_WeightQuant_Mfma_gfx950<512, 256, 256, 128, 16x16x128_f8f6f4, %s, %s, %s, "
@@ -722,6 +755,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
     snprintf(buf, n, "%s%s", plan.via_f16 ? "wq_f8_fnuz_to_f16+" : (plan.via_colb ? "wq_transpose_b8+" : ""),
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
+             : plan.route == ROUTE_I8_MFMA256 ? "wq_gemm_i8_mfma_256"
              : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"
              : plan.route == ROUTE_SKINNY ? "wq_gemm_skinny"
              : plan.route == ROUTE_SKINNY_WS

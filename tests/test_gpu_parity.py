@@ -347,6 +347,27 @@ def test_int8_bias_relu_requant(golden_gemm, port):
         assert name == "wq_gemm_i8_mfma_128"
         ref = port.gemm_i8_bias_requant(ar, b, bias, Mr, N, K, K, K, N, 2e-4, 1).reshape(Mr, N)
         np.testing.assert_array_equal(e, ref)
+    # the 256-tile kernel: forced at a small ragged size (all four functors), chosen by itself at 4096^3, and there
+    # bit-equal to the 128-tile kernel
+    Mr, Nr, Kr = 700, 512, 384
+    ar = rng.integers(-128, 128, (Mr, Kr)).astype(np.int8)
+    br = rng.integers(-128, 128, (Nr, Kr)).astype(np.int8)
+    biasr = rng.integers(-30000, 30001, Nr).astype(np.int32)
+    for relu in (False, True):
+        for bs in (None, biasr):
+            e, name = _run_i8(ar, br, Mr, Nr, Kr, 1e-3, bias=bs, relu=relu, flags=capi.FLAG_TILE_256)
+            assert name == "wq_gemm_i8_mfma_256"
+            ref = port.gemm_i8_bias_requant(ar, br, bs, Mr, Nr, Kr, Kr, Kr, Nr, 1e-3, int(relu)).reshape(Mr, Nr)
+            np.testing.assert_array_equal(e, ref)
+    big = 4096
+    ab = rng.integers(-128, 128, (big, big)).astype(np.int8)
+    bb = rng.integers(-128, 128, (big, big)).astype(np.int8)
+    e256, name = _run_i8(ab, bb, big, big, big, 5e-5)
+    assert name == "wq_gemm_i8_mfma_256"
+    e128, name = _run_i8(ab, bb, big, big, big, 5e-5, flags=capi.FLAG_TILE_128)
+    assert name == "wq_gemm_i8_mfma_128"
+    np.testing.assert_array_equal(e256, e128)
+    assert np.unique(e256).size > 50
     # a missing bias pointer is a malformed problem
     p = capi.fpAintB_problem(1, 1, None, 1, 128, 128, 128, a_dtype=capi.I8, b_dtype=capi.I8, c_dtype=capi.I8,
                              epilogue=capi.EPI_ADD_RELU_MUL_CLAMP, requant=0.03)
