@@ -550,46 +550,83 @@ __global__ __launch_bounds__(512) void wq_gemm_i8_mfma_256(const I8GemmParams p)
         for(int mt = 0; mt < 8; ++mt)
             acc[nt][mt] = i4_t{0, 0, 0, 0};
 
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    // Ping-pong: waves 0-3 and waves 4-7 (one of each per SIMD) run the same sequence of sections half a step apart,
+    // so that while one group issues its 32 MFMAs of a 64-deep step the other fetches the 12 fragments of its next
+    // step (and, once per K tile, issues its share of the LDS-DMA of tile t + 1).  Section ends are workgroup barriers;
+    // the late group passes one extra barrier first and the early group one extra at the end.
+    //   L(t, s): [s == 0: DMA of tile t + 1 into the other stage]  fragment reads of step s   [s == 1: own DMA landed]
+    //   M(t, s): 32 MFMAs
+    // The stage tile t + 1 goes to was last read in L(t - 1, 1) of both groups, which lies behind a barrier before
+    // either group reaches L(t, 0); tile t + 1 is first read in L(t + 1, 0), behind the barrier that ends L(t, 1) of
+    // both groups, where every wave has waited for its own DMA.
+    const int late = wave >> 2;
+    i4_t wf[4], af[8];
+    auto load_frags = [&](int buf, int s) __attribute__((always_inline)) {
         const uint8_t* sa = lds + buf * 2 * TILE;
         const uint8_t* sb = sa + TILE;
 #pragma unroll
-        for(int s = 0; s < 2; ++s) // two 64-deep MFMA steps per tile
+        for(int t = 0; t < 4; ++t)
         {
-            i4_t wf[4], af[8];
-#pragma unroll
-            for(int t = 0; t < 4; ++t)
-            {
-                const int nrow = wn * 64 + t * 16 + fr;
-                wf[t]          = *(const i4_t*)(sb + nrow * 128 + (((4 * s + fq) ^ (nrow & 7)) << 4));
-            }
-#pragma unroll
-            for(int t = 0; t < 8; ++t)
-            {
-                const int mrow = wm * 128 + t * 16 + fr;
-                af[t]          = *(const i4_t*)(sa + mrow * 128 + (((4 * s + fq) ^ (mrow & 7)) << 4));
-            }
-#pragma unroll
-            for(int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for(int nt = 0; nt < 4; ++nt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            const int nrow = wn * 64 + t * 16 + fr;
+            wf[t]          = *(const i4_t*)(sb + nrow * 128 + (((4 * s + fq) ^ (nrow & 7)) << 4));
         }
+#pragma unroll
+        for(int t = 0; t < 8; ++t)
+        {
+            const int mrow = wm * 128 + t * 16 + fr;
+            af[t]          = *(const i4_t*)(sa + mrow * 128 + (((4 * s + fq) ^ (mrow & 7)) << 4));
+        }
+    };
+    auto mfmas = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for(int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for(int nt = 0; nt < 4; ++nt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        // MFMAs have no side effects the optimiser knows of: an opaque use keeps them inside their section
+#pragma unroll
+        for(int mt = 0; mt < 8; ++mt)
+            asm volatile("" : "+v"(acc[0][mt]), "+v"(acc[1][mt]), "+v"(acc[2][mt]), "+v"(acc[3][mt]));
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto section_end = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     if(ntiles > 0)
     {
         stage(0, 0);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if(late)
+            __builtin_amdgcn_s_barrier();
         for(int t = 0; t < ntiles; ++t)
         {
             const int cur = t & 1;
+            // L(t, 0)
             if(t + 1 < ntiles)
                 stage(cur ^ 1, t + 1);
-            compute(cur);
-            __syncthreads();
+            load_frags(cur, 0);
+            section_end();
+            // M(t, 0)
+            mfmas();
+            section_end();
+            // L(t, 1)
+            load_frags(cur, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            section_end();
+            // M(t, 1)
+            mfmas();
+            section_end();
         }
+        if(!late)
+            __builtin_amdgcn_s_barrier();
     }
+    __syncthreads();
     // requantise into an LDS image of the tile (256 rows x 256 bytes, pitch 272), then stream whole rows out
     constexpr int PITCH = 256 + 16;
 #pragma unroll
