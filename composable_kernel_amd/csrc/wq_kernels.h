@@ -186,6 +186,41 @@ template <int NT, int MT, int RSTEP = 16, int CSTEP = 16>
 __device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t (&acc)[NT][MT], uint8_t* lds, int m0,
                                                  int n0, int row_w, int col_w, int fr, int fq, int wave, int lane)
 {
+    if constexpr(MT * RSTEP == 256)
+    {
+        if(p.partial && !p.direct_store)
+        {
+            // fp32 partial slab through LDS, 128 rows (128 KiB + padding) at a time: every wave-instruction stores one
+            // whole 1024-byte row of the slab instead of 16 pieces of 64 bytes
+            constexpr int PITCH = 1024 + 16, MTP = MT / 2;
+            float* slab = (float*)p.c + (size_t)blockIdx.z * p.M * p.ldc + (size_t)m0 * p.ldc + n0;
+#pragma unroll
+            for(int ph = 0; ph < 2; ++ph)
+            {
+                if(ph)
+                    __syncthreads(); // the rows of the first half have left LDS
+#pragma unroll
+                for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for(int mi = 0; mi < MTP; ++mi)
+                    {
+                        const int mt = ph * MTP + mi;
+                        const int r = row_w + mt * RSTEP + fr - ph * 128, c = col_w + nt * CSTEP + fq * 4;
+                        *(f4_t*)(lds + r * PITCH + c * 4) = acc[nt][mt];
+                    }
+                __syncthreads();
+#pragma unroll 4
+                for(int i = 0; i < 16; ++i)
+                {
+                    const int r  = wave * 16 + i;
+                    const f4_t v = *(const f4_t*)(lds + r * PITCH + lane * 16);
+                    if(m0 + ph * 128 + r < p.M)
+                        *(f4_t*)(slab + (size_t)(ph * 128 + r) * p.ldc + lane * 4) = v;
+                }
+            }
+            return;
+        }
+    }
     if(p.partial || p.direct_store)
     {
         tile_epilogue<NT, MT, RSTEP, CSTEP>(p, acc, m0 + row_w, n0 + col_w, fr, fq);
