@@ -418,6 +418,17 @@ def run_splitk(args):
 
     for _ in range(args.warmup):
         step()
+    # further untimed steps (~0.2 s, the same count on every rank) so that the GPU clocks have settled, as in the
+    # single-GPU run
+    torch.cuda.synchronize()
+    t_probe = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    probe = torch.tensor([time.perf_counter() - t_probe], dtype=torch.float64, device=dev)
+    dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+    extra = int(max(0, min(200, 0.2 / max(float(probe.item()), 1e-5)))) if args.ramp_launches > 0 else 0
+    for _ in range(extra):
+        step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -462,6 +473,7 @@ def run_splitk(args):
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_extra_untimed_steps": extra + 1,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True,
             "scaling": "strong",
