@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 // own the SAME 16 columns and a quarter of K each; their accumulators are summed through LDS and wave 0 applies
 // the epilogue.  grid (N / 16), 256 threads.  Only the M real rows of the activations are staged (lanes of the
 // zero rows read nothing), so M = 1 costs 2 K bytes of LDS; the image must fit (the planner uses this variant up to
-// 40 KiB).  Super-steps per wave must be a multiple of P.
+// 40 KiB).  K is split between the waves in units of P super-steps.
 template <int AK, int BKIND, int P>
 __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 {
@@ -223,9 +223,13 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
     const int n0   = blockIdx.x * 16;
 
     const int klen   = p.k_end - p.k_begin;
-    const int kw     = klen / 4;            // K range of one wave
-    const int nsteps = kw / KS;             // a multiple of P (host-checked), >= P
-    const int kbeg   = p.k_begin + wave * kw;
+    // K is dealt to the four waves in units of P super-steps (the host guarantees klen % (P KS) == 0 and at least four
+    // units); the first units % 4 waves take one unit more
+    const int units  = klen / (KS * P);
+    const int ubase  = units >> 2, urem = units & 3;
+    const int nsteps = (ubase + (wave < urem ? 1 : 0)) * P;
+    const int koff   = (wave * ubase + min(wave, urem)) * (P * KS); // first k of this wave, from k_begin
+    const int kbeg   = p.k_begin + koff;
 
     const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
                           (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 
     f4_t acc            = {0.f, 0.f, 0.f, 0.f};
     const bool live     = fr < p.M; // this lane's activation row exists
-    const uint8_t* a_ln = lds + (live ? fr : 0) * pitch + (wave * kw + fq * CH) * 2;
+    const uint8_t* a_ln = lds + (live ? fr : 0) * pitch + (koff + fq * CH) * 2;
     for(int t = 0; t < nsteps; t += P)
     {
 #pragma unroll
@@ -346,10 +350,12 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
     const int n0   = blockIdx.x * 16;
 
     const int klen    = p.k_end - p.k_begin;
-    const int kw      = klen / 4;            // K range of one wave
-    const int nsteps  = kw / KS;             // a multiple of P (host-checked), >= P
+    // K is dealt to the four waves in units of P super-steps, as in wq_gemm_skinny_ws
+    const int units   = klen / (KS * P);
+    const int ubase   = units >> 2, urem = units & 3;
+    const int nsteps  = (ubase + (wave < urem ? 1 : 0)) * P;
     const int nchunks = nsteps / SPC;
-    const int kbeg    = p.k_begin + wave * kw;
+    const int kbeg    = p.k_begin + (wave * ubase + min(wave, urem)) * (P * KS);
 
     const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
                           (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;

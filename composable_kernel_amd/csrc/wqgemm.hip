@@ -221,7 +221,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         // occupy the chip and K is short enough that splitting it across the grid would not pay for a second kernel
         // (every workgroup reads all M rows of the activations: N / 16 * M * K * 2 bytes from L2 in total, four times
         // what the grid-split kernel reads; measured break-even near 96 MB)
-        if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all % (4 * ks) == 0 && p->N % 16 == 0 &&
+        if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all / ks >= 4 && p->N % 16 == 0 &&
            p->N / 16 >= 128 && klen_all <= 8192 && (long)(p->N / 16) * p->M * klen_all * 2 <= 96L * 1000 * 1000)
         {
             plan.route = ROUTE_SKINNY_WS;
@@ -488,7 +488,9 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end;
         gp.epi     = epilogue_of(p);
         const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, klen = plan.k_end - plan.k_begin;
-        const int steps_per_wave = klen / 4 / ks;
+        // loads in flight = super-steps per unit of K dealt to a wave: as many as leave every wave at least one unit
+        const int steps   = klen / ks;
+        const int p_loads = steps % 4 == 0 && steps / 4 >= 4 ? 4 : (steps % 2 == 0 && steps / 2 >= 4 ? 2 : 1);
         // the whole activation image in LDS when it is small (no synchronisation in the loop), else chunk by chunk
         int lds_bytes = p->M * (klen * 2 + 16);
         if(lds_bytes > 40 * 1024)
@@ -496,7 +498,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         else if(lds_bytes < 4096)
             lds_bytes = 4096; // the cross-wave sum needs 4 x 64 x 16 bytes
         const int rc = wq::launch_skinny_ws(plan.ak, plan.bk, gp, dim3(p->N / 16), lds_bytes, s,
-                                            steps_per_wave % 4 == 0 ? 4 : (steps_per_wave % 2 == 0 ? 2 : 1));
+                                            p_loads);
         if(rc != WQ_OK)
             return fail(WQ_ERR_HIP, "small-M kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     }

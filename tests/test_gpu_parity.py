@@ -1003,11 +1003,13 @@ def test_small_m_kernel_long_k(port, M, K, a_dtype, b_dtype):
 @pytest.mark.parametrize("M", [1, 3, 9, 16])
 @pytest.mark.parametrize("a_dtype,b_dtype,K", [(capi.F16, capi.I4_PACKED, 1024), (capi.F16, capi.I4_PACKED, 1536),
                                                (capi.F16, capi.I4_PACKED, 4096), (capi.BF16, capi.I8, 2048),
+                                               (capi.F16, capi.I4_PACKED, 1152), (capi.F16, capi.I4_PACKED, 2816),
+                                               (capi.BF16, capi.I8, 1344),
                                                (capi.BF16, capi.I8, 1024), (capi.BF16, capi.I4_PACKED, 512),
                                                (capi.F16, capi.U8_OFFSET, 768)])
 def test_small_m_kernel_waves_split_k(port, M, a_dtype, b_dtype, K):
-    """M <= 16 with a wide N: one kernel, the four waves of a workgroup split K and sum through LDS (4, 2 or 1 loads
-    in flight depending on the super-steps per wave)."""
+    """M <= 16 with a wide N: one kernel, the four waves of a workgroup split K (in units of 4, 2 or 1 super-steps,
+    unevenly when the units do not divide by four) and sum through LDS."""
     rng = np.random.default_rng(7 * M + K + b_dtype)
     N = 2048
     lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
