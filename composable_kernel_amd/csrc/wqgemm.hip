@@ -222,7 +222,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         // (every workgroup reads all M rows of the activations: N / 16 * M * K * 2 bytes from L2 in total, four times
         // what the grid-split kernel reads; measured break-even near 96 MB)
         if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all / ks >= 4 && p->N % 16 == 0 &&
-           p->N / 16 >= 128 && klen_all <= 8192 && (long)(p->N / 16) * p->M * klen_all * 2 <= 96L * 1000 * 1000)
+           p->N / 16 >= 128 && (klen_all <= 8192 || (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024) && // (chunked variant: short K only)
+           (long)(p->N / 16) * p->M * klen_all * 2 <= 96L * 1000 * 1000)
         {
             plan.route = ROUTE_SKINNY_WS;
             return WQ_OK;
