@@ -1112,3 +1112,46 @@ def test_launch_is_graph_capturable(port):
     torch.cuda.synchronize()
     for _, _, a, a_t, c_t, exp, *_ in cases:
         np.testing.assert_array_equal(c_t.cpu().numpy().view(np.uint16), exp)
+
+
+def test_random_shapes_every_route_against_the_general_kernel():
+    """Seeded sweep over shapes, formats, epilogues and workspace use: whatever kernel the dispatcher picks must agree
+    bit for bit with the general kernel (the checker's own summation order) on integer-valued inputs, and must not
+    touch the guard rows behind C."""
+    rng = np.random.default_rng(20251111)
+    seen = {}
+    for case in range(90):
+        a_dtype = (capi.F16, capi.BF16)[int(rng.integers(0, 2))]
+        b_dtype = (capi.I4_PACKED, capi.I8, capi.U8_OFFSET)[int(rng.integers(0, 3))]
+        M = int(rng.choice([1, 2, 3, 7, 16, 17, 31, 33, 64, 65, 100, 128, 129, 255, 256, 257, 300, 511, 600]))
+        N = int(rng.choice([64, 128, 192, 256, 384, 512, 768, 1024, 2048, 2048]))
+        K = int(rng.choice([128, 256, 384, 512, 640, 1024, 1152, 2048]))
+        lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
+        q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+        if b_dtype == capi.I4_PACKED:
+            b = pack_on_device(q, K, N)
+        elif b_dtype == capi.U8_OFFSET:
+            b = (q.astype(np.int16) + 128).astype(np.uint8)
+        else:
+            b = q
+        cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+        a = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+        s = cvt(rng.integers(1, 3, N).astype(np.float32))
+        kw = dict(a_dtype=a_dtype, b_dtype=b_dtype)
+        if rng.integers(0, 3) == 0:
+            kw["use_workspace"] = False
+        elif rng.integers(0, 3) == 0 and K >= 512:
+            kw["k_batch"] = int(rng.integers(2, 5))
+        if rng.integers(0, 2):
+            kw["ldc"] = N + 8
+        got = run_fpaintb(a, b, s, M, N, K, **kw)
+        kw.pop("use_workspace", None)
+        ref = run_fpaintb(a, b, s, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC, **kw)
+        np.testing.assert_array_equal(got[:, :N], ref[:, :N], err_msg=f"case {case}: M={M} N={N} K={K} {kw}")
+        if "ldc" in kw:
+            assert (got[:, N:] == 0x7BFF).all()
+        p = capi.fpAintB_problem(1 << 20, 1 << 20, 1 << 20, 1 << 20, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype)
+        seen[capi.kernel_name(p)] = seen.get(capi.kernel_name(p), 0) + 1
+    # the sweep must have exercised every kernel family
+    for name in ("wq_gemm_skinny_ws", "wq_gemm_skinny", "wq_gemm_mfma_128"):
+        assert any(k.startswith(name) for k in seen), seen
