@@ -1155,3 +1155,25 @@ def test_random_shapes_every_route_against_the_general_kernel():
     # the sweep must have exercised every kernel family
     for name in ("wq_gemm_skinny_ws", "wq_gemm_skinny", "wq_gemm_mfma_128"):
         assert any(k.startswith(name) for k in seen), seen
+
+
+def test_random_shapes_int8_requant_against_the_general_kernel():
+    """The same sweep for the int8 requantisation family (tile kernels vs the general kernel, exact)."""
+    rng = np.random.default_rng(1411)
+    names = set()
+    for case in range(40):
+        M = int(rng.choice([1, 5, 64, 100, 128, 200, 256, 300, 513]))
+        N = int(rng.choice([128, 256, 384, 512, 1024]))
+        K = int(rng.choice([128, 256, 640, 1024]))
+        a = rng.integers(-128, 128, (M, K)).astype(np.int8)
+        b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        bias = rng.integers(-50000, 50001, N).astype(np.int32) if rng.integers(0, 2) else None
+        relu = bool(rng.integers(0, 2))
+        rq = float(rng.choice([1e-4, 1e-3, 0.03]))
+        flags = capi.FLAG_TILE_256 if (N % 256 == 0 and rng.integers(0, 2)) else 0
+        e, name = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu, flags=flags)
+        g, gname = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu, flags=capi.FLAG_GENERIC)
+        assert gname == GENERIC and name != GENERIC
+        names.add(name)
+        np.testing.assert_array_equal(e, g, err_msg=f"case {case}: M={M} N={N} K={K} bias={bias is not None} relu={relu}")
+    assert names == {"wq_gemm_i8_mfma_128", "wq_gemm_i8_mfma_256"}
