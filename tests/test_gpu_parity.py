@@ -1177,3 +1177,26 @@ def test_random_shapes_int8_requant_against_the_general_kernel():
         names.add(name)
         np.testing.assert_array_equal(e, g, err_msg=f"case {case}: M={M} N={N} K={K} bias={bias is not None} relu={relu}")
     assert names == {"wq_gemm_i8_mfma_128", "wq_gemm_i8_mfma_256"}
+
+
+def test_random_shapes_f8_int4_against_the_general_kernel():
+    """The same sweep for fp8 x int4 + MultiplyMultiply on the fp8 matrix core (both byte formats), on the exact input
+    set: activations in {-2 .. 2}, power-of-two per-column and per-row factors."""
+    rng = np.random.default_rng(650)
+    lut_fnuz = {0: 0x00, 1: 0x40, 2: 0x48, -1: 0xC0, -2: 0xC8}   # E4M3 FNUZ (bias 8)
+    lut_fn = {0: 0x00, 1: 0x38, 2: 0x40, -1: 0xB8, -2: 0xC0}     # OCP E4M3FN (bias 7)
+    for case in range(24):
+        M = int(rng.choice([65, 100, 256, 300, 512, 700]))
+        N = int(rng.choice([256, 512, 1024]))
+        K = int(rng.choice([128, 256, 640, 1024]))
+        fn = bool(rng.integers(0, 2))
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        bp = pack_on_device(q, K, N)
+        a_int = rng.integers(-2, 3, (M, K))
+        a = np.vectorize((lut_fn if fn else lut_fnuz).get)(a_int).astype(np.uint8)
+        d0 = (2.0 ** rng.integers(-3, 1, N)).astype(np.float32)
+        d1 = (2.0 ** rng.integers(-3, 1, M)).astype(np.float32)
+        kw = dict(a_dtype=capi.F8_E4M3FN if fn else capi.F8_FNUZ, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0, d1=d1)
+        got = run_fpaintb(a, bp, None, M, N, K, flags=0 if fn else capi.FLAG_F8_NO_SPECIALS, expect_kernel=F8_MFMA, **kw)
+        ref = run_fpaintb(a, bp, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC, **kw)
+        np.testing.assert_array_equal(got, ref, err_msg=f"case {case}: M={M} N={N} K={K} e4m3fn={fn}")
