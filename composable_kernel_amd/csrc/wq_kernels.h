@@ -74,7 +74,7 @@ __device__ __forceinline__ void tile_epilogue_k(const GemmParams& p, const f4_t 
     for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for(int mt = 0; mt < MT; ++mt)
-            if(m_base + mt * RSTEP + fr < p.M) // the last row tile of the 128-tile kernel may be partial
+            if(m_base + mt * RSTEP + fr < p.M && n_base + nt * CSTEP + fq * 4 < p.N) // partial last row / column tile (N % 4 == 0)
                 store_c4<KIND, BF16>(p.epi, p.c, p.ldc, acc[nt][mt], m_base + mt * RSTEP + fr, n_base + nt * CSTEP + fq * 4);
 }
 
@@ -89,7 +89,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
         for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for(int mt = 0; mt < MT; ++mt)
-                if(m_base + mt * RSTEP + fr < p.M)
+                if(m_base + mt * RSTEP + fr < p.M && n_base + nt * CSTEP + fq * 4 < p.N)
                     *(f4_t*)(slab + (size_t)(m_base + mt * RSTEP + fr) * p.ldc + n_base + nt * CSTEP + fq * 4) = acc[nt][mt];
         return;
     }
@@ -251,7 +251,8 @@ __device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// 128 x 128 x 64 MFMA kernel (any M >= 1: the last row tile may be partial; N and K in whole tiles)
+// 128 x 128 x 64 MFMA kernel (any M >= 1 and any N % 4 == 0: the last row and column tiles may be partial; K in
+// whole tiles)
 // ---------------------------------------------------------------------------------------------
 template <int AK, int BKIND>
 struct Mfma128
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     // scale of column 16 nt + (l & 15).
     ScaleReg<AK> sc[4];
     {
-        const uint16_t mine = p.scale ? ((const uint16_t*)p.scale)[n0 + wn * 64 + lane] : unit_scale_bits<AK>();
+        // (columns past N in a partial last column tile re-read column N - 1: valid memory, results never stored)
+        const uint16_t mine = p.scale ? ((const uint16_t*)p.scale)[min(n0 + wn * 64 + lane, p.N - 1)] : unit_scale_bits<AK>();
 #pragma unroll
         for(int nt = 0; nt < 4; ++nt)
             sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     {
         const int col   = (wave * B_INSTR + i) * B_COLS_PER_INSTR + lane / B_CHUNKS;
         const int chunk = (lane % B_CHUNKS) ^ ((col >> 2) & (B_CHUNKS - 1));
-        b_src[i]        = (const uint8_t*)p.b + (size_t)(n0 + col) * p.ldb_bytes +
+        b_src[i]        = (const uint8_t*)p.b + (size_t)min(n0 + col, p.N - 1) * p.ldb_bytes +
                    (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + chunk * 16;
     }
 

@@ -198,11 +198,11 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     plan.ak = p->a_dtype == WQ_BF16 ? wq::A_BF16 : wq::A_F16;
     plan.bk = p->b_dtype == WQ_I4_PACKED ? wq::B_I4P : (p->b_dtype == WQ_U8_OFFSET ? wq::B_U8O : wq::B_I8);
 
-    // The tiled MFMA kernel needs whole tiles along N and K (any M: its last row tile may be partial), K-contiguous
-    // operands and 16-byte aligned rows; everything else goes to the generic kernel.
+    // The tiled MFMA kernel needs whole tiles along K, N % 4 == 0 (its last row and column tiles may be partial),
+    // K-contiguous operands and 16-byte aligned rows; everything else goes to the generic kernel.
     const int b_row_align = p->b_dtype == WQ_I4_PACKED ? 32 : 16; // ldb elements per 16 bytes
     const bool tiled = is16(p->a_dtype) && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
-                       p->N % 128 == 0 && plan.k_begin % 64 == 0 &&
+                       p->N % 4 == 0 && plan.k_begin % 64 == 0 &&
                        plan.k_per_z % 64 == 0 && (plan.k_end - plan.k_begin) % 64 == 0 &&
                        p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
@@ -305,7 +305,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // up to about one workgroup per CU and at least four K tiles per slice.  Needs (and is dropped without) a workspace.
     if(plan.route == ROUTE_MFMA128 && !plan.partial && !plan.via_f16 && !plan.via_colb && !(p->flags & WQ_FLAG_TILE_128))
     {
-        const int wgs  = ((p->M + 127) / 128) * (p->N / 128);
+        const int wgs  = ((p->M + 127) / 128) * ((p->N + 127) / 128);
         const int klen = plan.k_end - plan.k_begin;
         // (up to 128 workgroups: about one per CU after the split; up to two per CU, which the 128-tile kernel runs
         // side by side, halves of a long K still pay: measured 15 - 20 % at 4096 <= K)
@@ -395,7 +395,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_per_z   = plan.k_per_z;
         gp.partial   = plan.partial ? 1 : 0;
         gp.tiles_m   = (p->M + tile - 1) / tile;
-        gp.tiles_n   = p->N / tile;
+        gp.tiles_n   = (p->N + tile - 1) / tile;
         gp.epi       = epilogue_of(p);
         gp.direct_store = (p->flags & WQ_FLAG_DIRECT_STORE) ? 1 : 0;
         gp.dbg          = g_dbg;

@@ -47,6 +47,9 @@ def test_is_supported_and_routes():
     assert capi.kernel_name(_problem(M=2)) == "wq_gemm_skinny_ws"
     assert capi.kernel_name(_problem(M=16)) == "wq_gemm_skinny_wsc"
     assert not capi.is_supported(_problem(flags=1 << 20))   # unknown flag bits are rejected
+    # N need only be a multiple of 4 for the 128-tile kernel (partial last column tile)
+    assert capi.kernel_name(_problem(M=300, N=16)) == "wq_gemm_mfma_128"
+    assert capi.kernel_name(_problem(M=300, N=1000)) == "wq_gemm_mfma_128"
     # ragged shapes fall back to the generic HIP kernel (still supported)
     p = _problem(M=33, N=17, K=72, lda=80, ldb=88, ldc=24)
     assert capi.is_supported(p) and capi.kernel_name(p) == "wq_gemm_generic"

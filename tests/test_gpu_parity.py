@@ -64,7 +64,7 @@ def test_golden_cases_generic_kernel_bit_exact(golden_gemm, tag):
     M, N, K, lda, ldb, ldc = (int(v) for v in g[f"{tag}_shape"])
     q = np.ascontiguousarray(g[f"{tag}_b"][:, :K])
     got = run_fpaintb(g[f"{tag}_a"], pack_on_device(q, K, N), g[f"{tag}_s"], M, N, K, lda=lda, ldc=ldc,
-                      expect_kernel=GENERIC)
+                      flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
     exp = np.zeros(M * ldc, np.uint16)
     exp[: g[f"{tag}_c"].size] = g[f"{tag}_c"]
     # compare only the M x N window (the padding columns of ldc keep their poison)
@@ -77,11 +77,12 @@ def test_golden_i8_weights_generic(golden_gemm):
     M, N, K, lda, ldb, ldc = (int(v) for v in g["fpaintb_i8_shape"])
     b = g["fpaintb_i8_b"]
     exp = g["fpaintb_i8_c"].reshape(M, N)
-    got = run_fpaintb(g["fpaintb_i8_a"], b, g["fpaintb_i8_s"], M, N, K, b_dtype=capi.I8, expect_kernel=GENERIC)
+    got = run_fpaintb(g["fpaintb_i8_a"], b, g["fpaintb_i8_s"], M, N, K, b_dtype=capi.I8, flags=capi.FLAG_GENERIC,
+                      expect_kernel=GENERIC)
     np.testing.assert_array_equal(got, exp)
     bu = (b.astype(np.int16) + 128).astype(np.uint8)   # example/64's UnsignedWeightPreprocessor
     got = run_fpaintb(g["fpaintb_i8_a"], bu, g["fpaintb_i8_s"], M, N, K, b_dtype=capi.U8_OFFSET,
-                      expect_kernel=GENERIC)
+                      flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
     np.testing.assert_array_equal(got, exp)
 
 
@@ -1124,7 +1125,7 @@ def test_random_shapes_every_route_against_the_general_kernel():
         a_dtype = (capi.F16, capi.BF16)[int(rng.integers(0, 2))]
         b_dtype = (capi.I4_PACKED, capi.I8, capi.U8_OFFSET)[int(rng.integers(0, 3))]
         M = int(rng.choice([1, 2, 3, 7, 16, 17, 31, 33, 64, 65, 100, 128, 129, 255, 256, 257, 300, 511, 600]))
-        N = int(rng.choice([64, 128, 192, 256, 384, 512, 768, 1024, 2048, 2048]))
+        N = int(rng.choice([16, 64, 100, 128, 192, 256, 384, 516, 768, 1024, 2048, 2048]))
         K = int(rng.choice([128, 256, 384, 512, 640, 1024, 1152, 2048]))
         lo, hi = (-8, 8) if b_dtype == capi.I4_PACKED else (-128, 128)
         q = rng.integers(lo, hi, (N, K)).astype(np.int8)
