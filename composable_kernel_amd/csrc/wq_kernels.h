@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
 // byte per element a 128-deep K tile has the same 128-byte rows as the fp16 kernel's 64-deep tile, so
 // staging, swizzle and fragment addressing are shared; both operands go HBM -> LDS by LDS-DMA and
 // straight into v_mfma_i32_16x16x64_i8 (16 consecutive k per lane and operand).  Weights are the
-// first operand: lane l owns C[m = l & 15][n = 4 (l >> 4) + j] and stores 4 int8 at once.  Any M >= 1 (the last
-// row tile may be partial); N and K in whole tiles.
+// first operand: lane l owns C[m = l & 15][n = 4 (l >> 4) + j] and stores 4 int8 at once.  Any M >= 1 and any
+// N % 4 == 0 (the last row and column tiles may be partial); K in whole tiles.
 // ---------------------------------------------------------------------------------------------
 struct I8GemmParams
 {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
         const int chunk = (lane & 7) ^ (row & 7);
         // rows past M (a partial last row tile) re-read row M - 1: valid memory, results never stored
         a_src[i]        = (const uint8_t*)p.a + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk * 16;
-        b_src[i]        = (const uint8_t*)p.b + (size_t)(n0 + row) * p.ldb + chunk * 16;
+        b_src[i]        = (const uint8_t*)p.b + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 16; // likewise past N
     }
     auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         uint8_t* sa = lds + buf * 2 * TILE;
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
             uint32_t pk = 0;
 #pragma unroll
             for(int j = 0; j < 4; ++j)
-                pk |= (uint32_t)(uint8_t)requant_epilogue(p.kind, p.requant, acc[nt][mt][j], p.bias, n + j) << (8 * j);
-            if(m < p.M)
+                pk |= (uint32_t)(uint8_t)requant_epilogue(p.kind, p.requant, acc[nt][mt][j], p.bias, min(n + j, p.N - 1)) << (8 * j);
+            if(m < p.M && n < p.N) // partial last row / column tile (N % 4 == 0)
                 *(uint32_t*)((int8_t*)p.c + (size_t)m * p.ldc + n) = pk;
         }
 }

@@ -137,7 +137,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         if(plan.partial)
             return fail(WQ_ERR_UNSUPPORTED, "split-K is not implemented for the int8 requant GEMM");
         const bool tiled_i8 = p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
-                              p->N % 128 == 0 && p->K % 128 == 0 && p->lda % 16 == 0 && p->ldb % 16 == 0 &&
+                              p->N % 4 == 0 && p->K % 128 == 0 && p->lda % 16 == 0 && p->ldb % 16 == 0 &&
                               p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 &&
                               (uintptr_t)p->c % 4 == 0 && !(p->flags & WQ_FLAG_GENERIC);
         plan.route = tiled_i8 ? ROUTE_I8_MFMA128 : ROUTE_GENERIC;
@@ -531,7 +531,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.a = p->a, gp.b = p->b, gp.c = p->c;
         gp.M = p->M, gp.N = p->N, gp.K = p->K;
         gp.lda = p->lda, gp.ldb = p->ldb, gp.ldc = p->ldc;
-        gp.tiles_m = (p->M + 127) / 128, gp.tiles_n = p->N / 128;
+        gp.tiles_m = (p->M + 127) / 128, gp.tiles_n = (p->N + 127) / 128;
         gp.group_m = gp.tiles_m >= 8 ? 8 : gp.tiles_m;
         gp.requant = p->requant_scale;
         gp.kind    = p->epilogue;

@@ -1164,7 +1164,7 @@ def test_random_shapes_int8_requant_against_the_general_kernel():
     names = set()
     for case in range(40):
         M = int(rng.choice([1, 5, 64, 100, 128, 200, 256, 300, 513]))
-        N = int(rng.choice([128, 256, 384, 512, 1024]))
+        N = int(rng.choice([16, 100, 128, 256, 384, 512, 1024]))
         K = int(rng.choice([128, 256, 640, 1024]))
         a = rng.integers(-128, 128, (M, K)).astype(np.int8)
         b = rng.integers(-128, 128, (N, K)).astype(np.int8)
