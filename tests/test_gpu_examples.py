@@ -106,6 +106,9 @@ def test_reference_client_example30_sources_dropin(name):
     ("gemm_fpAintB", 0, 1, 1, 2, 0, 1, 256, 256, 512, -1, -1, -1),
     ("gemm_fpAintB", 3, 1, 1, 2, 0, 1, 256, 384, 512, -1, -1, -1),
     ("gemm_fpAintB", 2, 1, 1, 1, 0, 0, 100, 72, 200, -1, -1, -1),
+    ("gemm_fpAintB", 0, 1, 1, 1, 0, 1, 300, 16, 1024, -1, -1, -1),    # narrow N, ragged M: partial tiles + planner split-K
+    ("gemm_fpAintB", 0, 1, 1, 2, 0, 1, 16, 2048, 8192, -1, -1, -1),   # small M: streaming kernel
+    ("gemm_quantization", 3, 1, 1, 2, 0, 1, 300, 100, 512, -1, -1, -1),
     ("gemm_splitk", 0, 1, 1, 1, 0, 1, 256, 256, 2048, -1, -1, -1, 4),
     ("gemm_quantization", 3, 1, 1, 2, 0, 1, 512, 512, 512, -1, -1, -1),
     ("gemm_multiply_multiply", 8, 1, 1, 2, 0, 1, 256, 256, 512, -1, -1, 0, 0, -1),
