@@ -98,3 +98,14 @@ def test_pack_int4_host_matches_checker(port):
         raise AssertionError("out-of-range value accepted")
     except capi.WqError as e:
         assert e.status == capi.ERR_INVALID
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """There is no CPU fallback: without libwqgemm.so the binding must refuse to import (checked in a child process
+    that is pointed at a path holding no library)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WQGEMM_LIB=str(tmp_path / "libwqgemm.so"))
+    r = subprocess.run([sys.executable, "-c", "import composable_kernel_amd.capi"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode != 0 and "ImportError" in r.stderr
