@@ -109,3 +109,21 @@ def test_missing_library_fails_loudly(tmp_path):
     r = subprocess.run([sys.executable, "-c", "import composable_kernel_amd.capi"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode != 0 and "ImportError" in r.stderr
+
+
+def test_product_never_touches_the_checker():
+    """The CPU checker under oracle/ is test infrastructure: nothing in the package, the C++ sources, the headers or
+    the examples may import, include or link it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for top in ("composable_kernel_amd", "include", "examples"):
+        for dirpath, _, files in os.walk(os.path.join(root, top)):
+            if "_ref_build" in dirpath:
+                continue
+            for f in files:
+                if not f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")) and f != "Makefile":
+                    continue
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"\boracle\b|wq_oracle|libck_ref", text):
+                    offenders.append(os.path.relpath(os.path.join(dirpath, f), root))
+    assert not offenders, offenders
