@@ -71,6 +71,41 @@ def test_is_supported_and_routes():
     assert b"int4" in capi.lib.wqgemm_last_error()
 
 
+def _i8_problem(**kw):
+    fake = 0x10000
+    d = dict(a=fake, b=fake, scale=None, c=fake, M=4096, N=4096, K=4096, a_dtype=capi.I8, b_dtype=capi.I8,
+             c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=0.03)
+    d.update(kw)
+    return capi.fpAintB_problem(d.pop("a"), d.pop("b"), d.pop("scale"), d.pop("c"), d.pop("M"), d.pop("N"),
+                                d.pop("K"), **d)
+
+
+def test_int8_requant_routes():
+    """int8 x int8 -> int8 behind the (Add_)Activation_Mul_Clamp epilogues: which kernel serves which shape, and
+    what the validation rejects."""
+    assert capi.kernel_name(_i8_problem()) == "wq_gemm_i8_mfma_256"
+    assert capi.kernel_name(_i8_problem(M=256, N=256, K=256)) == "wq_gemm_i8_mfma_128"     # the example's size
+    assert capi.kernel_name(_i8_problem(M=256, N=256, K=256, flags=capi.FLAG_TILE_256)) == "wq_gemm_i8_mfma_256"
+    assert capi.kernel_name(_i8_problem(M=1000)) == "wq_gemm_i8_mfma_128"                  # partial last row tile
+    assert capi.kernel_name(_i8_problem(N=1000)) == "wq_gemm_i8_mfma_128"                  # partial last column tile
+    assert capi.kernel_name(_i8_problem(N=1002)) == "wq_gemm_generic"
+    assert capi.kernel_name(_i8_problem(K=200, lda=200, ldb=200)) == "wq_gemm_generic"
+    assert capi.kernel_name(_i8_problem(b_layout=capi.ROW_MAJOR)) == "wq_gemm_generic"     # mk_kn
+    assert capi.kernel_name(_i8_problem(a_layout=capi.COL_MAJOR)) == "wq_gemm_generic"     # km_nk
+    assert capi.is_supported(_i8_problem(epilogue=capi.EPI_RELU_MUL_CLAMP))
+    # the bias variants need their int32 bias vector
+    assert not capi.is_supported(_i8_problem(epilogue=capi.EPI_ADD_RELU_MUL_CLAMP))
+    assert b"bias" in capi.lib.wqgemm_last_error()
+    assert capi.is_supported(_i8_problem(epilogue=capi.EPI_ADD_RELU_MUL_CLAMP, d0=0x10000))
+    assert capi.is_supported(_i8_problem(epilogue=capi.EPI_ADD_ACT_MUL_CLAMP, d0=0x10000))
+    # int8 A only pairs with int8 B, int8 C and a requantising epilogue; no split-K
+    assert not capi.is_supported(_i8_problem(epilogue=capi.EPI_PASSTHROUGH))
+    assert not capi.is_supported(_i8_problem(c_dtype=capi.F16))
+    assert not capi.is_supported(_i8_problem(b_dtype=capi.I4_PACKED))
+    assert not capi.is_supported(_i8_problem(k_batch=2))
+    assert capi.workspace_bytes(_i8_problem()) == 0
+
+
 def test_splitk_workspace_and_kread():
     assert capi.splitk_kread(65536, 8) == 8192
     assert capi.splitk_kread(437, 3, 8) == 152
