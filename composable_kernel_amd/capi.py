@@ -39,6 +39,7 @@ EXPORTS = (
     "wqgemm_version", "wqgemm_last_error", "wqgemm_is_supported", "wqgemm_workspace_bytes",
     "wqgemm_launch", "wqgemm_run_timed", "wqgemm_type_string", "wqgemm_kernel_name",
     "wqgemm_pack_int4", "wqgemm_pack_int4_host", "wqgemm_reduce_finalize", "wqgemm_splitk_kread",
+    "wqgemm_run_timed_rotating",
 )
 
 
@@ -53,6 +54,7 @@ class Problem(C.Structure):
         ("epilogue", C.c_int32), ("requant_scale", C.c_float),
         ("d0", C.c_void_p), ("d1", C.c_void_p),
         ("k_batch", C.c_int32), ("k_begin", C.c_int32), ("k_end", C.c_int32), ("flags", C.c_int32),
+        ("ldd0", C.c_int32), ("ldd1", C.c_int32),
     ]
 
 
@@ -79,6 +81,8 @@ def _load() -> C.CDLL:
     L.wqgemm_launch.argtypes = [P, C.c_void_p, C.c_void_p]
     L.wqgemm_run_timed.restype = C.c_int
     L.wqgemm_run_timed.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.wqgemm_run_timed_rotating.restype = C.c_int
+    L.wqgemm_run_timed_rotating.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.wqgemm_type_string.restype = C.c_int
     L.wqgemm_type_string.argtypes = [P, C.c_char_p, C.c_size_t]
     L.wqgemm_kernel_name.restype = C.c_int
@@ -124,6 +128,14 @@ def run_timed(p: Problem, workspace: int | None, stream: int | None, cold: int, 
     return float(ms.value)
 
 
+def run_timed_rotating(p: Problem, workspace: int | None, stream: int | None, cold: int, repeat: int,
+                       rotating_count: int) -> float:
+    """Median ms over `repeat` individually timed launches cycling through `rotating_count` copies of A and B."""
+    ms = C.c_float(0.0)
+    check(lib.wqgemm_run_timed_rotating(C.byref(p), workspace, stream, cold, repeat, rotating_count, C.byref(ms)))
+    return float(ms.value)
+
+
 def type_string(p: Problem) -> str:
     buf = C.create_string_buffer(512)
     lib.wqgemm_type_string(C.byref(p), buf, 512)
@@ -159,7 +171,8 @@ def splitk_kread(K: int, k_batch: int, granule: int = 64) -> int:
 
 def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, lda=None, ldb=None,
                     ldc=None, epilogue=EPI_PASSTHROUGH, d0=None, d1=None, k_batch=1, k_begin=0,
-                    k_end=0, c_dtype=None, b_layout=COL_MAJOR, a_layout=ROW_MAJOR, requant=0.0, flags=0) -> Problem:
+                    k_end=0, c_dtype=None, b_layout=COL_MAJOR, a_layout=ROW_MAJOR, requant=0.0, flags=0,
+                    ldd0=0, ldd1=0) -> Problem:
     """Fill a Problem from raw device pointers (ints).  Strides default to packed tensors."""
     p = Problem()
     p.a_dtype, p.b_dtype, p.scale_dtype = a_dtype, b_dtype, a_dtype
@@ -173,4 +186,5 @@ def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, 
     p.epilogue, p.requant_scale = epilogue, requant
     p.d0, p.d1 = d0, d1
     p.k_batch, p.k_begin, p.k_end, p.flags = k_batch, k_begin, k_end, flags
+    p.ldd0, p.ldd1 = ldd0, ldd1
     return p

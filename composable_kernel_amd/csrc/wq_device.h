@@ -230,6 +230,10 @@ struct EpilogueArgs
     float requant; // Activation_Mul_Clamp
     const void* d0;
     const void* d1;
+    // Element (m, n) of a D operand.  16-bit kinds (2, 6 - 9): both row-major, d[m * ldd + n].  MultiplyMultiply kinds
+    // (3, 4): d0 row-major d0[m * ldd0 + n], d1 column-major d1[m + n * ldd1].  ldd = 0 is the broadcast form
+    // (one value per column, or per row for the column-major d1).
+    int ldd0, ldd1;
 };
 
 // unary_element_wise_operation.hpp:443-452 (host form: true exp and true division, in fp32 here)
@@ -260,24 +264,24 @@ __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, 
     case 1: return fast_gelu(x);
     case 2: {
         // element_wise_operation.hpp:277-295: FastGelu(c * d0 + d1), separate multiply and add
-        const float t = x * load_d_as_f32(e.d0, n, e.c_dtype);
-        return fast_gelu(t + load_d_as_f32(e.d1, n, e.c_dtype));
+        const float t = x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
+        return fast_gelu(t + load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
     }
     case 3: {
         // element_wise_operation.hpp:252-275: c * d0 * d1 left to right
-        const float t = x * ((const float*)e.d0)[n];
-        return t * ((const float*)e.d1)[m];
+        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
+        return t * ((const float*)e.d1)[m + n * e.ldd1];
     }
     case 4: {
-        const float t = x * ((const float*)e.d0)[n];
-        return fast_gelu(t * ((const float*)e.d1)[m]);
+        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
+        return fast_gelu(t * ((const float*)e.d1)[m + n * e.ldd1]);
     }
     // binary_element_wise_operation.hpp: Add :78-85, AddFastGelu :511-522, Multiply (float x bhalf), MultiplyFastGelu
     // :578-590 -- the second operand is d0[n] of the output's 16-bit type
-    case 6: return x + load_d_as_f32(e.d0, n, e.c_dtype);
-    case 7: return fast_gelu(x + load_d_as_f32(e.d0, n, e.c_dtype));
-    case 8: return x * load_d_as_f32(e.d0, n, e.c_dtype);
-    case 9: return fast_gelu(x * load_d_as_f32(e.d0, n, e.c_dtype));
+    case 6: return x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
+    case 7: return fast_gelu(x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
+    case 8: return x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
+    case 9: return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
     default: return x;
     }
 }
@@ -290,27 +294,27 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
         return fast_gelu(x);
     else if constexpr(KIND == 2)
     {
-        const float t = x * load_d_as_f32(e.d0, n, e.c_dtype);
-        return fast_gelu(t + load_d_as_f32(e.d1, n, e.c_dtype));
+        const float t = x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
+        return fast_gelu(t + load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
     }
     else if constexpr(KIND == 3)
     {
-        const float t = x * ((const float*)e.d0)[n];
-        return t * ((const float*)e.d1)[m];
+        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
+        return t * ((const float*)e.d1)[m + n * e.ldd1];
     }
     else if constexpr(KIND == 4)
     {
-        const float t = x * ((const float*)e.d0)[n];
-        return fast_gelu(t * ((const float*)e.d1)[m]);
+        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
+        return fast_gelu(t * ((const float*)e.d1)[m + n * e.ldd1]);
     }
     else if constexpr(KIND == 6)
-        return x + load_d_as_f32(e.d0, n, e.c_dtype);
+        return x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
     else if constexpr(KIND == 7)
-        return fast_gelu(x + load_d_as_f32(e.d0, n, e.c_dtype));
+        return fast_gelu(x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
     else if constexpr(KIND == 8)
-        return x * load_d_as_f32(e.d0, n, e.c_dtype);
+        return x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
     else if constexpr(KIND == 9)
-        return fast_gelu(x * load_d_as_f32(e.d0, n, e.c_dtype));
+        return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
     else
         return x;
 }

@@ -3,6 +3,7 @@
 // launch path; errors are reported by status code plus a thread-local message.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -45,7 +46,7 @@ int fail(int code, const char* fmt, ...)
             return fail(WQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
     } while(0)
 
-void* g_dbg = nullptr; // diagnostic stamp buffer (wqgemm_debug_section_cycles)
+thread_local void* g_dbg = nullptr; // diagnostic stamp buffer, set only inside wqgemm_debug_section_cycles on the calling thread
 
 enum Route
 {
@@ -77,6 +78,33 @@ struct Plan
 };
 
 bool is16(int dt) { return dt == WQ_F16 || dt == WQ_BF16; }
+
+// Epilogues of the floating-point family and the D vectors each one reads.
+int check_fp_epilogue(const wqgemm_problem* p)
+{
+    switch(p->epilogue)
+    {
+    case WQ_EPI_PASSTHROUGH:
+    case WQ_EPI_FASTGELU: break;
+    case WQ_EPI_MULTIPLY_ADD_FASTGELU:
+    case WQ_EPI_MULTIPLY_MULTIPLY:
+    case WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU:
+        if(!p->d0 || !p->d1)
+            return fail(WQ_ERR_INVALID, "epilogue %d needs d0 and d1", p->epilogue);
+        break;
+    case WQ_EPI_ADD:
+    case WQ_EPI_ADD_FASTGELU:
+    case WQ_EPI_MULTIPLY:
+    case WQ_EPI_MULTIPLY_FASTGELU:
+        if(!p->d0)
+            return fail(WQ_ERR_INVALID, "epilogue %d needs d0", p->epilogue);
+        break;
+    default: return fail(WQ_ERR_UNSUPPORTED, "epilogue %d is not valid for this dtype", p->epilogue);
+    }
+    if(p->ldd0 < 0 || p->ldd1 < 0)
+        return fail(WQ_ERR_INVALID, "ldd0 and ldd1 must be 0 (broadcast) or a positive leading dimension");
+    return WQ_OK;
+}
 
 // Validate and choose a kernel.  Returns WQ_OK and fills plan, or an error status with message.
 int make_plan(const wqgemm_problem* p, Plan& plan)
@@ -167,6 +195,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         if(p->scale && p->scale_dtype != p->a_dtype)
             return fail(WQ_ERR_UNSUPPORTED, "scale dtype must equal the activation dtype");
     }
+    if(!is16(p->a_dtype) && p->scale)
+        return fail(WQ_ERR_UNSUPPORTED, "fp8 activations take their scales through the d0/d1 epilogue: scale must be NULL");
     if(!slice)
     {
         // (a K-slice launch stores fp32 partials; its epilogue runs in wqgemm_reduce_finalize)
@@ -175,25 +205,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         if(is16(p->a_dtype) && p->c_dtype != p->a_dtype)
             return fail(WQ_ERR_UNSUPPORTED, "C dtype must equal the activation dtype");
     }
-    switch(p->epilogue)
-    {
-    case WQ_EPI_PASSTHROUGH:
-    case WQ_EPI_FASTGELU: break;
-    case WQ_EPI_MULTIPLY_ADD_FASTGELU:
-    case WQ_EPI_MULTIPLY_MULTIPLY:
-    case WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU:
-        if(!p->d0 || !p->d1)
-            return fail(WQ_ERR_INVALID, "epilogue %d needs d0 and d1", p->epilogue);
-        break;
-    case WQ_EPI_ADD:
-    case WQ_EPI_ADD_FASTGELU:
-    case WQ_EPI_MULTIPLY:
-    case WQ_EPI_MULTIPLY_FASTGELU:
-        if(!p->d0)
-            return fail(WQ_ERR_INVALID, "epilogue %d needs d0", p->epilogue);
-        break;
-    default: return fail(WQ_ERR_UNSUPPORTED, "epilogue %d is not valid for this dtype", p->epilogue);
-    }
+    if(const int rc = check_fp_epilogue(p); rc != WQ_OK)
+        return rc;
 
     plan.ak = p->a_dtype == WQ_BF16 ? wq::A_BF16 : wq::A_F16;
     plan.bk = p->b_dtype == WQ_I4_PACKED ? wq::B_I4P : (p->b_dtype == WQ_U8_OFFSET ? wq::B_U8O : wq::B_I8);
@@ -264,7 +277,9 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // 8-bit weights stored (K, N) row-major (the B layout of client_example/30_gemm_bf16Aint8B): the matrix-core
     // kernels want K contiguous, so the launch first transposes B into the workspace (HBM-bound, 2 K N bytes);
     // without a workspace the general kernel runs.
-    if(plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) && is16(p->a_dtype) && !plan.partial &&
+    // Split-K by the caller (k_batch > 1) combines with it: the slabs come first in the workspace, the copy after them.
+    if(plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) && is16(p->a_dtype) && !slice &&
+       plan.k_per_z % 64 == 0 &&
        p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_ROW_MAJOR && p->b_dtype != WQ_I4_PACKED &&
        p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % 16 == 0 && p->ldc % 4 == 0 &&
        (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0)
@@ -340,6 +355,8 @@ wq::EpilogueArgs epilogue_of(const wqgemm_problem* p)
     e.requant = p->requant_scale;
     e.d0      = p->d0;
     e.d1      = p->d1;
+    e.ldd0    = p->ldd0;
+    e.ldd1    = p->ldd1;
     return e;
 }
 
@@ -363,9 +380,10 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.lda       = p->lda;
         if(plan.via_colb)
         {
+            uint8_t* colb = (uint8_t*)workspace + (plan.partial ? (size_t)plan.k_batch * p->M * p->N * sizeof(float) : 0);
             hipLaunchKernelGGL(wq::wq_transpose_b8, dim3(p->N / 64, p->K / 64), dim3(256), 0, s, (const uint8_t*)p->b, p->ldb,
-                               p->K, p->N, (uint8_t*)workspace);
-            gp.b         = workspace;
+                               p->K, p->N, colb);
+            gp.b         = colb;
             gp.ldb_bytes = p->K;
         }
         if(plan.via_f16)
@@ -634,7 +652,7 @@ size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
     if(make_plan(p, plan) != WQ_OK)
         return 0;
     if(plan.partial && !plan.to_c)
-        return (size_t)plan.k_batch * p->M * p->N * sizeof(float);
+        return (size_t)plan.k_batch * p->M * p->N * sizeof(float) + (plan.via_colb ? (size_t)p->K * p->N : 0);
     if(plan.via_f16)
         return ((size_t)p->M * p->K + p->N) * sizeof(uint16_t);
     if(plan.via_colb)
@@ -707,6 +725,98 @@ int wqgemm_run_timed(const wqgemm_problem* p, void* workspace, void* stream, int
     WQ_HIP(hipEventDestroy(e0));
     WQ_HIP(hipEventDestroy(e1));
     *avg_ms = ms / (float)nrepeat;
+    return WQ_OK;
+}
+
+// Bytes an operand occupies as the kernels address it (last row/column ends at its last element).
+static size_t a_span_bytes(const wqgemm_problem* p)
+{
+    const size_t sz   = (p->a_dtype == WQ_F16 || p->a_dtype == WQ_BF16) ? 2 : 1;
+    const size_t rows = p->a_layout == WQ_ROW_MAJOR ? p->M : p->K, cols = p->a_layout == WQ_ROW_MAJOR ? p->K : p->M;
+    return ((rows - 1) * (size_t)p->lda + cols) * sz;
+}
+static size_t b_span_bytes(const wqgemm_problem* p)
+{
+    const size_t rows = p->b_layout == WQ_COL_MAJOR ? p->N : p->K, cols = p->b_layout == WQ_COL_MAJOR ? p->K : p->N;
+    const size_t elems = (rows - 1) * (size_t)p->ldb + cols;
+    return p->b_dtype == WQ_I4_PACKED ? (elems + 1) / 2 : elems;
+}
+
+int wqgemm_run_timed_rotating(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters, int nrepeat,
+                              int rotating_count, float* median_ms)
+{
+    if(!median_ms || nrepeat <= 0)
+        return fail(WQ_ERR_INVALID, "median_ms must be non-null and nrepeat positive");
+    Plan plan;
+    if(const int rc = make_plan(p, plan); rc != WQ_OK)
+        return rc;
+    if(rotating_count < 1)
+        rotating_count = 1;
+    if(rotating_count > 64)
+        return fail(WQ_ERR_INVALID, "rotating_count %d: at most 64 copies", rotating_count);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t na = a_span_bytes(p), nb = b_span_bytes(p);
+    const void* a_copies[64];
+    const void* b_copies[64];
+    a_copies[0] = p->a, b_copies[0] = p->b;
+    int made = 1, status = WQ_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float times[4096];
+    if(nrepeat > 4096)
+        nrepeat = 4096;
+#define WQ_TRY(expr)                                                                      \
+    if(status == WQ_OK)                                                                   \
+    {                                                                                     \
+        hipError_t e_ = (expr);                                                           \
+        if(e_ != hipSuccess)                                                              \
+            status = fail(WQ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    }
+    for(; made < rotating_count && status == WQ_OK; ++made)
+    {
+        void *pa = nullptr, *pb = nullptr;
+        WQ_TRY(hipMalloc(&pa, na));
+        WQ_TRY(hipMalloc(&pb, nb));
+        a_copies[made] = pa, b_copies[made] = pb;
+        WQ_TRY(hipMemcpy(pa, p->a, na, hipMemcpyDeviceToDevice));
+        WQ_TRY(hipMemcpy(pb, p->b, nb, hipMemcpyDeviceToDevice));
+        if(status != WQ_OK)
+        {
+            (void)hipFree(pa);
+            (void)hipFree(pb);
+            break;
+        }
+    }
+    wqgemm_problem q = *p;
+    for(int i = 0; i < cold_iters && status == WQ_OK; ++i)
+        status = wqgemm_launch(&q, workspace, stream);
+    WQ_TRY(hipEventCreate(&e0));
+    WQ_TRY(hipEventCreate(&e1));
+    for(int i = 0; i < nrepeat && status == WQ_OK; ++i)
+    {
+        // untimed preprocessing of the iteration: step to the next copy of A and B
+        q.a = a_copies[i % made], q.b = b_copies[i % made];
+        WQ_TRY(hipDeviceSynchronize());
+        WQ_TRY(hipEventRecord(e0, s));
+        if(status == WQ_OK)
+            status = wqgemm_launch(&q, workspace, stream);
+        WQ_TRY(hipEventRecord(e1, s));
+        WQ_TRY(hipEventSynchronize(e1));
+        WQ_TRY(hipEventElapsedTime(&times[i], e0, e1));
+    }
+#undef WQ_TRY
+    if(e0)
+        (void)hipEventDestroy(e0);
+    if(e1)
+        (void)hipEventDestroy(e1);
+    for(int i = 1; i < made; ++i)
+    {
+        (void)hipFree(const_cast<void*>(a_copies[i]));
+        (void)hipFree(const_cast<void*>(b_copies[i]));
+    }
+    if(status != WQ_OK)
+        return status;
+    std::sort(times, times + nrepeat);
+    *median_ms = nrepeat % 2 == 1 ? times[(nrepeat - 1) / 2] : 0.5f * (times[(nrepeat - 1) / 2] + times[(nrepeat - 1) / 2 + 1]);
     return WQ_OK;
 }
 
@@ -828,6 +938,8 @@ int wqgemm_reduce_finalize(const wqgemm_problem* p, const float* partials, int32
         return fail(WQ_ERR_INVALID, "reduce_finalize: need k_batch >= 1, N %% 4 == 0, ldc %% 4 == 0");
     if(p->c_dtype != WQ_F16 && p->c_dtype != WQ_BF16 && p->c_dtype != WQ_F32)
         return fail(WQ_ERR_UNSUPPORTED, "reduce_finalize: C must be fp16, bf16 or fp32");
+    if(const int rc = check_fp_epilogue(p); rc != WQ_OK) // (the int8 requantisation kinds have no split-K form)
+        return rc;
     return launch_reduce(p, partials, k_batch, (hipStream_t)stream);
 }
 

@@ -20,6 +20,12 @@
 //        stands where DeviceGemmMultiD_Xdl_CShuffle_V3<f8,f8,(f32,f32)> does
 //        (impl/device_gemm_multiple_d_xdl_cshuffle_v3.hpp)
 //
+//   DeviceGemmV2R1_WeightQuant_gfx950    : DeviceGemmV2R1          (example/35 gemm_xdl_splitk_reduce_bf16A_i8B)
+//        stands where DeviceGemm_Xdl_CShuffleV3R1<bf16, int8> does
+//        (impl/device_gemm_xdl_cshuffle_v3r1.hpp:28-700): KSplit before the functors, fp32 slabs in the
+//        caller's workspace (GetWorkSpaceSize / SetWorkSpacePointer), reduce + convert afterwards
+//   DeviceGemmSplitK_WeightQuant_gfx950  : DeviceGemmSplitK        (profiler gemm_splitk: trailing KBatch)
+//
 // Conventions kept from the reference (device_fpAintB_gemm_wmma.hpp:424-433,497-501,594-630):
 // Argument holds raw non-owning pointers and copies of the functors; IsSupportedArgument returns
 // false for problems the engine cannot run; Invoker::Run throws std::runtime_error on an
@@ -43,6 +49,8 @@
 #include "ck/tensor_operation/gpu/device/device_gemm_dequantB.hpp"
 #include "ck/tensor_operation/gpu/device/device_gemm_multiple_d.hpp"
 #include "ck/tensor_operation/gpu/device/device_gemm_multiple_abd.hpp"
+#include "ck/tensor_operation/gpu/device/device_gemm_splitk.hpp"
+#include "ck/tensor_operation/gpu/device/device_gemm_v2.hpp"
 #include "ck/tensor_operation/gpu/element/element_wise_operation.hpp"
 
 #include "wqgemm.h"
@@ -159,8 +167,13 @@ inline float run(const wqgemm_problem& prob, void* workspace, const StreamConfig
         throw std::runtime_error(std::string("wrong! ") + who + " has invalid setting: " + wqgemm_last_error());
     if(cfg.time_kernel_)
     {
-        float ms     = 0.f;
-        const int rc = wqgemm_run_timed(&prob, workspace, cfg.stream_id_, cfg.cold_niters_, cfg.nrepeat_, &ms);
+        float ms = 0.f;
+        // StreamConfig::flush_cache selects the reference's other timing mode: rotating copies of A and B, one event
+        // pair per launch, median (include/ck/host_utility/flush_cache.hpp:107-235)
+        const int rc = cfg.flush_cache
+                           ? wqgemm_run_timed_rotating(&prob, workspace, cfg.stream_id_, cfg.cold_niters_, cfg.nrepeat_,
+                                                       cfg.rotating_count, &ms)
+                           : wqgemm_run_timed(&prob, workspace, cfg.stream_id_, cfg.cold_niters_, cfg.nrepeat_, &ms);
         if(rc != WQ_OK)
             throw std::runtime_error(std::string(who) + ": " + wqgemm_last_error());
         return ms;
@@ -187,14 +200,30 @@ struct Argument : public BaseArgument
     // (client_example/30_gemm_bf16Aint8B) still reach the matrix-core kernels.  A workspace handed over with
     // SetWorkSpacePointer takes precedence; split-K workspaces stay the caller's (device_base.hpp:60-67).
     std::shared_ptr<void> owned_workspace;
-    void AllocateOptionalWorkspace()
+    // with_splitk_slabs: also for k_batch > 1, for interfaces whose clients have no workspace call at all
+    // (DeviceGemmSplitK: profiler/include/profiler/profile_gemm_splitk_impl.hpp:160-176)
+    void AllocateOptionalWorkspace(bool with_splitk_slabs = false)
     {
-        if(prob.k_batch > 1)
+        if(prob.k_batch > 1 && !with_splitk_slabs)
             return;
         const size_t bytes = wqgemm_workspace_bytes(&prob);
-        void* ptr          = nullptr;
-        if(bytes != 0 && hipMalloc(&ptr, bytes) == hipSuccess)
+        if(bytes == 0)
+            return;
+        void* ptr           = nullptr;
+        const hipError_t rc = hipMalloc(&ptr, bytes);
+        if(rc == hipSuccess)
             owned_workspace = std::shared_ptr<void>(ptr, [](void* q) { (void)hipFree(q); });
+        else
+        {
+            (void)hipGetLastError();
+            static bool told = false;
+            if(!told)
+                std::cerr << "wqgemm: could not allocate " << bytes << " bytes of operator-owned scratch ("
+                          << hipGetErrorString(rc) << "): "
+                          << (prob.k_batch > 1 ? "split-K cannot run" : "the general kernel will run, far slower")
+                          << "; hand a workspace over with SetWorkSpacePointer" << std::endl;
+            told = true;
+        }
     }
     void* Workspace() const { return p_workspace_ ? p_workspace_ : owned_workspace.get(); }
 };
@@ -446,7 +475,9 @@ struct DeviceGemmMultiABD_WeightQuant_gfx950
         p.lda = StrideAs[0], p.ldb = StrideBs[0], p.ldc = StrideE; // StrideBs[1] == 0: per-column scale
         p.a = p_as[0], p.b = p_bs[0], p.scale = p_bs[1], p.c = p_e;
         p.epilogue = wq_detail::unary_epilogue_of<CDEElementwiseOperation>();
-        p.k_batch  = 1;
+        if(StrideBs[1] != 0) // a scale per (k, n) is not a per-column scale: refused by IsSupportedArgument
+            p.epilogue = -1;
+        p.k_batch = 1;
         return arg;
     }
     static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiABD_WeightQuant_gfx950"}; }
@@ -556,7 +587,8 @@ struct DeviceGemmMultiABD_gfx950
     static Argument MakeArgument(std::array<const void*, 1> p_as, std::array<const void*, NumB> p_bs,
                                  std::array<const void*, NumD> p_ds, void* p_e, index_t M, index_t N, index_t K,
                                  std::array<index_t, 1> StrideAs, std::array<index_t, NumB> StrideBs,
-                                 std::array<index_t, NumD>, index_t StrideE, PassThrough, BOp, CDEElementwiseOperation)
+                                 std::array<index_t, NumD> StrideDs, index_t StrideE, PassThrough, BOp,
+                                 CDEElementwiseOperation)
     {
         Argument arg;
         wqgemm_problem& p = arg.prob;
@@ -570,14 +602,20 @@ struct DeviceGemmMultiABD_gfx950
         p.M = M, p.N = N, p.K = K;
         p.lda = StrideAs[0], p.ldb = StrideBs[0], p.ldc = StrideE;
         p.a = p_as[0], p.b = p_bs[0], p.c = p_e;
-        if constexpr(ScaleOnB)
-            p.scale = p_bs[1]; // lengths (K, N), stride 0 along K: N values
-        if constexpr(NumD >= 1)
-            p.d0 = p_ds[0];
-        if constexpr(NumD >= 2)
-            p.d1 = p_ds[1];
         p.epilogue = kEpilogue;
-        p.k_batch  = 1;
+        if constexpr(ScaleOnB)
+        {
+            p.scale = p_bs[1]; // lengths (K, N), stride 0 along K: N values
+            if(StrideBs[1] != 0) // a scale per (k, n) is not a per-column scale: refused by IsSupportedArgument
+                p.epilogue = -1;
+        }
+        // D tensors are row-major (M, N): stride 0 = one value per column, otherwise the row pitch of a full matrix
+        // (client_example/30_gemm_bf16Aint8B/gemm_bias_xdl_bf16_i8.cpp:84,128 hands over a full one)
+        if constexpr(NumD >= 1)
+            p.d0 = p_ds[0], p.ldd0 = StrideDs[0];
+        if constexpr(NumD >= 2)
+            p.d1 = p_ds[1], p.ldd1 = StrideDs[1];
+        p.k_batch = 1;
         arg.AllocateOptionalWorkspace();
         return arg;
     }
@@ -616,8 +654,9 @@ struct DeviceGemmMultiABD_gfx950
 template <typename ALayout, typename BLayout, typename ELayout, typename ADataType, typename BDataType,
           typename EDataType, typename CDEElementwiseOperation, bool AssumeNoFnuzSpecials = false>
 struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
-    : public DeviceGemmMultipleD<ALayout, BLayout, ck::Tuple<ELayout, ELayout>, ELayout, ADataType, BDataType,
-                                 ck::Tuple<float, float>, EDataType, element_wise::PassThrough,
+    : public DeviceGemmMultipleD<ALayout, BLayout,
+                                 ck::Tuple<tensor_layout::gemm::RowMajor, tensor_layout::gemm::ColumnMajor>, ELayout,
+                                 ADataType, BDataType, ck::Tuple<float, float>, EDataType, element_wise::PassThrough,
                                  element_wise::PassThrough, CDEElementwiseOperation>
 {
     using Argument    = wq_detail::Argument;
@@ -632,11 +671,12 @@ struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
             return WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU;
     }
 
-    // D0: per-column (row-major, stride 0); D1: per-row (column-major, stride 0) --
-    // example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8.cpp:43-47,152-153
+    // D0 row-major (M, N), D1 column-major (M, N); stride 0 = D0 per column, D1 per row, the form
+    // example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8.cpp:43-47,152-153 uses; other strides address
+    // full matrices
     static Argument MakeArgument(const void* p_a, const void* p_b, std::array<const void*, 2> p_ds, void* p_e,
                                  index_t M, index_t N, index_t K, index_t StrideA, index_t StrideB,
-                                 std::array<index_t, 2>, index_t StrideE, PassThrough, PassThrough,
+                                 std::array<index_t, 2> StrideDs, index_t StrideE, PassThrough, PassThrough,
                                  CDEElementwiseOperation)
     {
         Argument arg;
@@ -652,6 +692,7 @@ struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
         p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideE;
         p.a = p_a, p.b = p_b, p.c = p_e;
         p.d0 = p_ds[0], p.d1 = p_ds[1];
+        p.ldd0 = StrideDs[0], p.ldd1 = StrideDs[1];
         p.epilogue = epilogue();
         p.k_batch  = 1;
         p.flags    = AssumeNoFnuzSpecials ? WQ_FLAG_F8_NO_SPECIALS : 0;
@@ -682,6 +723,165 @@ struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
         return wqgemm_workspace_bytes(&dynamic_cast<const Argument*>(p_arg)->prob);
     }
     std::string GetTypeString() const override { return "DeviceGemmMultiplyMultiply_WeightQuant_gfx950<F8, I4x2>"; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Split-K over weight-quantized B:  C = c_op( sum over KBatch slices of A[M,K] * cvt_A(B[K,N]) [, D0] )
+// A fp16 / bf16, B int8 (or offset uint8 / packed int4) with no weight scale -- ReferenceGemm's arithmetic with
+// BDataType = int8 (library/include/ck/library/reference_tensor_operation/cpu/reference_gemm.hpp:60-108), the problem of
+// example/35_splitK_gemm/gemm_xdl_splitk_reduce_bf16A_i8B.cpp.  Slice z covers [z KRead, min(K, (z+1) KRead)),
+// KRead = ceil(K / (KBatch * 64)) * 64 (gridwise_gemm_xdl_cshuffle_v3.hpp:192-197), fp32 slabs [KBatch][M][N] are
+// summed in ascending order and converted (device_gemm_xdl_cshuffle_v3r1.hpp:209-270).  KBatch = 1 runs one pass
+// with no slabs.
+// ---------------------------------------------------------------------------------------------
+namespace wq_detail {
+template <typename COp, int NumD>
+constexpr int splitk_epilogue()
+{
+    namespace ew = ck::tensor_operation::element_wise;
+    if constexpr(NumD == 0)
+        return unary_epilogue_of<COp>();
+    else if constexpr(NumD == 1)
+    {
+        if constexpr(std::is_same_v<COp, ew::Add>)
+            return WQ_EPI_ADD;
+        else if constexpr(std::is_same_v<COp, ew::AddFastGelu>)
+            return WQ_EPI_ADD_FASTGELU;
+        else if constexpr(std::is_same_v<COp, ew::Multiply>)
+            return WQ_EPI_MULTIPLY;
+        else if constexpr(std::is_same_v<COp, ew::MultiplyFastGelu>)
+            return WQ_EPI_MULTIPLY_FASTGELU;
+        else
+            return -1;
+    }
+    else
+        return -1;
+}
+
+inline void fill_unscaled(wqgemm_problem& p, int a_dtype, int b_dtype, int c_dtype, int a_layout, int b_layout, int c_layout,
+                          const void* p_a, const void* p_b, void* p_c, index_t M, index_t N, index_t K, index_t StrideA,
+                          index_t StrideB, index_t StrideC, index_t KBatch, int epilogue)
+{
+    p.a_dtype = a_dtype, p.b_dtype = b_dtype, p.scale_dtype = a_dtype, p.c_dtype = c_dtype;
+    p.a_layout = a_layout, p.b_layout = b_layout, p.c_layout = c_layout;
+    p.M = M, p.N = N, p.K = K;
+    p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideC;
+    p.a = p_a, p.b = p_b, p.scale = nullptr, p.c = p_c;
+    p.epilogue = epilogue;
+    p.k_batch  = KBatch < 1 ? 1 : KBatch;
+}
+} // namespace wq_detail
+
+template <typename ALayout, typename BLayout, typename DsLayout, typename CLayout, typename ADataType,
+          typename BDataType, typename DsDataType, typename CDataType, typename AElementwiseOperation,
+          typename BElementwiseOperation, typename CElementwiseOperation>
+struct DeviceGemmV2R1_WeightQuant_gfx950
+    : public DeviceGemmV2R1<ALayout, BLayout, DsLayout, CLayout, ADataType, BDataType, DsDataType, CDataType,
+                            AElementwiseOperation, BElementwiseOperation, CElementwiseOperation>
+{
+    using Argument = wq_detail::Argument;
+    using Invoker  = wq_detail::Invoker;
+    static constexpr index_t NumDTensor = DsDataType::Size();
+    static constexpr int kEpilogue      = wq_detail::splitk_epilogue<CElementwiseOperation, NumDTensor>();
+    static_assert(std::is_same_v<AElementwiseOperation, element_wise::PassThrough> &&
+                      std::is_same_v<BElementwiseOperation, element_wise::PassThrough>,
+                  "A and B element-wise operations must be PassThrough");
+    static_assert(kEpilogue >= 0, "unsupported C element-wise operation / D tensor count");
+
+    static Argument MakeArgument(const ADataType* p_a, const BDataType* p_b, std::array<const void*, NumDTensor> p_ds,
+                                 CDataType* p_c, index_t M, index_t N, index_t K, index_t StrideA, index_t StrideB,
+                                 std::array<index_t, NumDTensor> StrideDs, index_t StrideC, index_t KBatch,
+                                 AElementwiseOperation, BElementwiseOperation, CElementwiseOperation)
+    {
+        Argument arg;
+        wq_detail::fill_unscaled(arg.prob, wq_detail::dtype_of<ADataType>::value, wq_detail::dtype_of<BDataType>::value,
+                                 wq_detail::dtype_of<CDataType>::value, wq_detail::layout_of<ALayout>(),
+                                 wq_detail::layout_of<BLayout>(), wq_detail::layout_of<CLayout>(), p_a, p_b, p_c, M, N, K,
+                                 StrideA, StrideB, StrideC, KBatch, kEpilogue);
+        if constexpr(NumDTensor == 1)
+            arg.prob.d0 = p_ds[0], arg.prob.ldd0 = StrideDs[0]; // row-major (M, N) like C; stride 0 = one value per column
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmV2R1_WeightQuant_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument>
+    MakeArgumentPointer(const void* p_a, const void* p_b, std::array<const void*, NumDTensor> p_ds, void* p_c, index_t M,
+                        index_t N, index_t K, index_t StrideA, index_t StrideB, std::array<index_t, NumDTensor> StrideDs,
+                        index_t StrideC, index_t KSplit, AElementwiseOperation a_op, BElementwiseOperation b_op,
+                        CElementwiseOperation c_op) override
+    {
+        return std::make_unique<Argument>(MakeArgument(static_cast<const ADataType*>(p_a), static_cast<const BDataType*>(p_b),
+                                                       p_ds, static_cast<CDataType*>(p_c), M, N, K, StrideA, StrideB, StrideDs,
+                                                       StrideC, KSplit, a_op, b_op, c_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    // KBatch * M * N * 4 bytes of fp32 slabs for KBatch > 1 (device_gemm_xdl_cshuffle_v3r1.hpp:686-694), plus K * N for
+    // the K-contiguous copy of row-major 8-bit weights; the caller allocates and hands it over
+    size_t GetWorkSpaceSize(const BaseArgument* p_arg) const override
+    {
+        return wqgemm_workspace_bytes(&dynamic_cast<const Argument*>(p_arg)->prob);
+    }
+    std::string GetTypeString() const override
+    {
+        return std::string("DeviceGemmV2R1_WeightQuant_gfx950<") + ALayout::name[0] + BLayout::name[0] + CLayout::name[0] +
+               ", " + (wq_detail::dtype_of<ADataType>::value == WQ_BF16 ? "BF16" : "F16") + ", " +
+               (wq_detail::dtype_of<BDataType>::value == WQ_I4_PACKED ? "I4x2" : "I8") + ", SplitKReduce, Epilogue" +
+               std::to_string(kEpilogue) + ">";
+    }
+};
+
+template <typename ALayout, typename BLayout, typename CLayout, typename ADataType, typename BDataType,
+          typename CDataType, typename CElementwiseOperation, typename ComputeType = CDataType>
+struct DeviceGemmSplitK_WeightQuant_gfx950
+    : public DeviceGemmSplitK<ALayout, BLayout, CLayout, ADataType, BDataType, CDataType, element_wise::PassThrough,
+                              element_wise::PassThrough, CElementwiseOperation, ComputeType>
+{
+    using Argument    = wq_detail::Argument;
+    using Invoker     = wq_detail::Invoker;
+    using PassThrough = element_wise::PassThrough;
+    static constexpr int kEpilogue = wq_detail::unary_epilogue_of<CElementwiseOperation>();
+    static_assert(kEpilogue >= 0, "CElementwiseOperation must be PassThrough or FastGelu");
+
+    // The interface has no workspace call (its reference instances accumulate with atomics into C:
+    // device_gemm_xdl_splitk_c_shuffle.hpp), so the argument owns the fp32 slabs.
+    static Argument MakeArgument(const ADataType* p_a, const BDataType* p_b, CDataType* p_c, index_t M, index_t N,
+                                 index_t K, index_t StrideA, index_t StrideB, index_t StrideC, PassThrough, PassThrough,
+                                 CElementwiseOperation, index_t KBatch)
+    {
+        Argument arg;
+        wq_detail::fill_unscaled(arg.prob, wq_detail::dtype_of<ADataType>::value, wq_detail::dtype_of<BDataType>::value,
+                                 wq_detail::dtype_of<CDataType>::value, wq_detail::layout_of<ALayout>(),
+                                 wq_detail::layout_of<BLayout>(), wq_detail::layout_of<CLayout>(), p_a, p_b, p_c, M, N, K,
+                                 StrideA, StrideB, StrideC, KBatch, kEpilogue);
+        arg.AllocateOptionalWorkspace(/*with_splitk_slabs=*/true);
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmSplitK_WeightQuant_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument> MakeArgumentPointer(const void* p_a, const void* p_b, void* p_c, index_t M, index_t N,
+                                                      index_t K, index_t StrideA, index_t StrideB, index_t StrideC,
+                                                      PassThrough a_op, PassThrough b_op, CElementwiseOperation c_op,
+                                                      index_t KBatch) override
+    {
+        return std::make_unique<Argument>(MakeArgument(static_cast<const ADataType*>(p_a), static_cast<const BDataType*>(p_b),
+                                                       static_cast<CDataType*>(p_c), M, N, K, StrideA, StrideB, StrideC, a_op,
+                                                       b_op, c_op, KBatch));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    std::string GetTypeString() const override
+    {
+        return std::string("DeviceGemmSplitK_WeightQuant_gfx950<") + ALayout::name[0] + BLayout::name[0] + CLayout::name[0] +
+               ", " + (wq_detail::dtype_of<ADataType>::value == WQ_BF16 ? "BF16" : "F16") + ", " +
+               (wq_detail::dtype_of<BDataType>::value == WQ_I4_PACKED ? "I4x2" : "I8") + ", SlabReduce>";
+    }
 };
 
 } // namespace device

@@ -110,6 +110,14 @@ typedef struct wqgemm_problem
     int32_t k_batch;
     int32_t k_begin, k_end;
     int32_t flags; /* 0, or one of WQ_FLAG_TILE_* to pin the tile shape (testing / tuning) */
+    /* Leading dimensions of d0 / d1 in elements; 0 (the default) = the broadcast forms named at wq_epilogue.
+     * Non-zero: a full (M, N) D tensor as CK's descriptors address it
+     * (include/ck/tensor_operation/gpu/device/impl/device_gemm_multiple_d_xdl_cshuffle.hpp:206-229) -- the 16-bit
+     * epilogues (2, 6 - 9) read row-major d[m*ldd + n]; MultiplyMultiply (3, 4) reads d0 row-major d0[m*ldd0 + n]
+     * and d1 column-major d1[m + n*ldd1] (the DsLayout Tuple<Row, Col> of
+     * example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8.cpp:43-47).  Ignored by the int32 bias of the
+     * requantisation epilogues (always one value per column). */
+    int32_t ldd0, ldd1;
 } wqgemm_problem;
 
 /* Library version string, e.g. "wqgemm 0.1 (gfx950)". */
@@ -126,7 +134,7 @@ int wqgemm_is_supported(const wqgemm_problem* p);
 
 /* Bytes of device workspace wqgemm_launch can use:
  *  - k_batch*M*N*4 when the caller sets k_batch > 1 (required: the launch fails with WQ_ERR_WORKSPACE
- *    without it);
+ *    without it), plus K*N for tile-aligned row-major (K x N) 8-bit weights (their K-contiguous copy follows the slabs);
  *  - kb*M*N*4 when the planner itself splits K (small-M problems, and short grids of the 128-tile kernel; kb chosen
  *    so the grid fills the chip;
  *    optional: without it the launch runs the whole K range as one slice);
@@ -151,6 +159,16 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream);
  * StreamConfig defaults cold 5 / repeat 50: include/ck/stream_config.hpp:9-19). */
 int wqgemm_run_timed(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters,
                      int nrepeat, float* avg_ms);
+
+/* The timing mode that keeps cache reuse across iterations out of the figure: rotating_count copies of A and B
+ * (the originals plus rotating_count - 1 device copies this call allocates and frees; at most 64) are used in
+ * turn, each of the nrepeat launches is bracketed by its own pair of HIP events after a device synchronisation,
+ * and *median_ms receives the median.  Replaces launch_and_time_kernel_with_preprocess + RotatingMemWrapper with
+ * StreamConfig::flush_cache set (include/ck/host_utility/flush_cache.hpp:17-95,107-235; used from
+ * impl/device_gemm_xdl_cshuffle_v3r1.hpp:339-374).  The reference's instruction-cache invalidation kernel
+ * between iterations has no counterpart here. */
+int wqgemm_run_timed_rotating(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters,
+                              int nrepeat, int rotating_count, float* median_ms);
 
 /* Instance name, written to buf (NUL-terminated, truncated to n).  Replaces
  * BaseOperator::GetTypeString (device_base.hpp:47; impl/device_fpAintB_gemm_wmma.hpp:662-706). */

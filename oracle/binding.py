@@ -88,6 +88,11 @@ class Checker:
         self._bf16 = sig("gemm_bf16_i8", None,
                          [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p] + tail)
         self._f8 = sig("gemm_f8_i8_mm", None, [_u8p, _i8p, _f32p, _f32p, _u16p] + [C.c_int] * 7 + tail)
+        self._bf16_dmat = sig("gemm_bf16_i8_dmat", None,
+                              [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 +
+                              [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + tail)
+        if not self._threaded:
+            self._bf16_unscaled = sig("gemm_bf16_i8_unscaled", None, [_u16p, _i8p, _u16p] + [C.c_int] * 7)
         if self._threaded:
             self._partial = sig("fpAintB_gemm_f16_partial", None,
                                 [_u16p, _i8p, _u16p, _f32p] + [C.c_int] * 7)
@@ -144,6 +149,23 @@ class Checker:
         self._bf16(a.ravel(), b0.ravel(), pb1, e, M, N, K, lda, b_sk, b_sn, lde, epilogue, p0, p1,
                    *self._t(nthreads))
         return e
+
+    def gemm_bf16_i8_dmat(self, a, b0, b1, M, N, K, lda, b_sk, b_sn, lde, epilogue, d0, ldd0, d1=None, ldd1=0,
+                          nthreads=None) -> np.ndarray:
+        """gemm_bf16_i8 with D tensors addressed as row-major (M, N) matrices of row stride ldd (0 = per column)."""
+        e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.uint16)
+        d0 = np.ascontiguousarray(d0, np.uint16)
+        d1 = np.ascontiguousarray(d1, np.uint16) if d1 is not None else None
+        pb1 = np.ascontiguousarray(b1, np.uint16).ctypes.data if b1 is not None else None
+        self._bf16_dmat(a.ravel(), b0.ravel(), pb1, e, M, N, K, lda, b_sk, b_sn, lde, epilogue, d0.ctypes.data, ldd0,
+                        d1.ctypes.data if d1 is not None else None, ldd1, *self._t(nthreads))
+        return e
+
+    def gemm_bf16_i8_unscaled(self, a, b, M, N, K, lda, b_sk, b_sn, ldc) -> np.ndarray:
+        """Reference-backed checker only: ReferenceGemm<bhalf, int8, bhalf, float> straight on int8 B (example/35)."""
+        c = np.zeros(1 + (M - 1) * ldc + (N - 1), dtype=np.uint16)
+        self._bf16_unscaled(a.ravel(), b.ravel(), c, M, N, K, lda, b_sk, b_sn, ldc)
+        return c
 
     def gemm_f8_i8_mm(self, a, b, d0, d1, M, N, K, lda, ldb, lde, fastgelu, nthreads=None) -> np.ndarray:
         e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.uint16)

@@ -276,6 +276,70 @@ void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1,
         }
 }
 
+// Same path with the D tensors addressed as the examples' d_m_n(m, n) over a row-major (M, N) descriptor of row
+// stride ldd (example/60_gemm_multi_ABD/gemm_multi_ABD_xdl_bias_fastgelu_bf16_i8.cpp:86,140,263); 0 = per column.
+void ckref_gemm_bf16_i8_dmat(const uint16_t* a, const int8_t* b0, const uint16_t* b1, uint16_t* e,
+                             int M, int N, int K, int lda, int b_sk, int b_sn, int lde, int epilogue,
+                             const uint16_t* d0, int ldd0, const uint16_t* d1, int ldd1)
+{
+    auto ta  = load2<bhalf_t>(a, M, K, lda, 1);
+    auto tb0 = load2<int8_t>(b0, K, N, b_sk, b_sn);
+    Tensor<bhalf_t> tb(desc2(K, N, b_sk, b_sn));
+    for(int n = 0; n < N; ++n)
+        for(int k = 0; k < K; ++k)
+        {
+            if(b1)
+                ew::Multiply{}(tb(k, n), tb0(k, n), bhalf_t(b1[n]));
+            else
+                PT{}(tb(k, n), tb0(k, n));
+        }
+    Tensor<float> tc(desc2(M, N, N, 1));
+    using Ref = ck::tensor_operation::host::ReferenceGemm<bhalf_t, bhalf_t, float, float, PT, PT, PT>;
+    auto ref = Ref{};
+    auto inv = ref.MakeInvoker();
+    inv.Run(ref.MakeArgument(ta, tb, tc, PT{}, PT{}, PT{}));
+    Tensor<bhalf_t> td0(desc2(M, N, ldd0, 1)), td1(desc2(M, N, ldd1, 1));
+    if(d0)
+        for(size_t i = 0; i < td0.mData.size(); ++i)
+            td0.mData[i] = bhalf_t(d0[i]);
+    if(d1)
+        for(size_t i = 0; i < td1.mData.size(); ++i)
+            td1.mData[i] = bhalf_t(d1[i]);
+    for(int m = 0; m < M; ++m)
+        for(int n = 0; n < N; ++n)
+        {
+            bhalf_t y;
+            if(epilogue == 2)
+                ew::MultiplyAddFastGelu{}(y, tc(m, n), td0(m, n), td1(m, n));
+            else if(epilogue == 3)
+                ew::Add{}(y, tc(m, n), td0(m, n));
+            else if(epilogue == 4)
+                ew::AddFastGelu{}(y, tc(m, n), td0(m, n));
+            else if(epilogue == 5)
+                ew::Multiply{}(y, tc(m, n), td0(m, n));
+            else
+                ew::MultiplyFastGelu{}(y, tc(m, n), td0(m, n));
+            e[static_cast<size_t>(m) * lde + n] = y;
+        }
+}
+
+// example/35_splitK_gemm/gemm_xdl_splitk_reduce_bf16A_i8B.cpp:55-61 + run_gemm_splitk_reduce_multi_d_example.inc:260-266
+// verify path: ReferenceGemm<bhalf, int8, bhalf, float, PT, PT, PT> straight on the int8 B (no scale), C bhalf.
+void ckref_gemm_bf16_i8_unscaled(const uint16_t* a, const int8_t* b, uint16_t* c, int M, int N, int K, int lda,
+                                 int b_sk, int b_sn, int ldc)
+{
+    auto ta = load2<bhalf_t>(a, M, K, lda, 1);
+    auto tb = load2<int8_t>(b, K, N, b_sk, b_sn);
+    Tensor<bhalf_t> tc(desc2(M, N, ldc, 1));
+    using Ref = ck::tensor_operation::host::ReferenceGemm<bhalf_t, int8_t, bhalf_t, float, PT, PT, PT>;
+    auto ref = Ref{};
+    auto inv = ref.MakeInvoker();
+    inv.Run(ref.MakeArgument(ta, tb, tc, PT{}, PT{}, PT{}));
+    for(int m = 0; m < M; ++m)
+        for(int n = 0; n < N; ++n)
+            c[static_cast<size_t>(m) * ldc + n] = tc(m, n);
+}
+
 // example/65 verify path with an int8-held int4 B: c = ReferenceGemm<f8,int8,float,float>;
 // e = half(c * d0[n] * d1[m]) (MultiplyMultiply), optionally followed by FastGelu<half,float>
 // applied to the fp32 product (fastgelu != 0: e = half(FastGelu(c*d0*d1))).

@@ -465,7 +465,9 @@ void wqo_gemm_i8_bias_requant(const int8_t* a, const int8_t* b, const int32_t* b
  *            5 Multiply<bhalf>(float, bhalf)          binary_element_wise_operation.hpp:180-188
  *            6 MultiplyFastGelu<bhalf,float,bhalf>    binary_element_wise_operation.hpp:578-590
  *   b1 == NULL: the "multiply" instances, B = PassThrough(b0) (int8 -> bhalf, exact), scale in the epilogue.
- * B element (k,n) at k*b_sk + n*b_sn. */
+ * B element (k,n) at k*b_sk + n*b_sn.  D element (m,n) at m*ldd + n: the examples' d_m_n(m, n) over a row-major
+ * descriptor with row stride StrideD (gemm_multi_ABD_xdl_bias_fastgelu_bf16_i8.cpp:86,140,263), 0 = one value per
+ * column. */
 typedef struct
 {
     const uint16_t* a;
@@ -474,6 +476,7 @@ typedef struct
     uint16_t* e;
     const uint16_t *d0, *d1;
     int K, lda, b_sk, b_sn, lde, epilogue;
+    int ldd0, ldd1;
 } bf16_ctx;
 
 static void bf16_i8_mn(void* p, int m, int n)
@@ -487,21 +490,23 @@ static void bf16_i8_mn(void* p, int m, int n)
         const float vb = x->b1 ? wqo_bf16_to_f32(wqo_multiply_bf16(q, x->b1[n])) : (float)q;
         acc += va * vb;
     }
+    const uint16_t* d0 = x->d0 ? x->d0 + (size_t)m * x->ldd0 : 0;
+    const uint16_t* d1 = x->d1 ? x->d1 + (size_t)m * x->ldd1 : 0;
     uint16_t y;
     if(x->epilogue == 0)
         y = wqo_f32_to_bf16(acc);
     else if(x->epilogue == 1)
         y = wqo_f32_to_bf16(wqo_fastgelu(acc));
     else if(x->epilogue == 2)
-        y = wqo_multiply_add_fastgelu_bf16(acc, x->d0[n], x->d1[n]);
+        y = wqo_multiply_add_fastgelu_bf16(acc, d0[n], d1[n]);
     else if(x->epilogue == 3)
-        y = wqo_f32_to_bf16(acc + wqo_bf16_to_f32(x->d0[n]));
+        y = wqo_f32_to_bf16(acc + wqo_bf16_to_f32(d0[n]));
     else if(x->epilogue == 4)
-        y = wqo_f32_to_bf16(wqo_fastgelu(acc + wqo_bf16_to_f32(x->d0[n])));
+        y = wqo_f32_to_bf16(wqo_fastgelu(acc + wqo_bf16_to_f32(d0[n])));
     else if(x->epilogue == 5)
-        y = wqo_f32_to_bf16(acc * wqo_bf16_to_f32(x->d0[n]));
+        y = wqo_f32_to_bf16(acc * wqo_bf16_to_f32(d0[n]));
     else
-        y = wqo_f32_to_bf16(wqo_fastgelu(acc * wqo_bf16_to_f32(x->d0[n])));
+        y = wqo_f32_to_bf16(wqo_fastgelu(acc * wqo_bf16_to_f32(d0[n])));
     x->e[(size_t)m * x->lde + n] = y;
 }
 
@@ -509,7 +514,16 @@ void wqo_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1, u
                       int N, int K, int lda, int b_sk, int b_sn, int lde, int epilogue,
                       const uint16_t* d0, const uint16_t* d1, int nthreads)
 {
-    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue};
+    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue, 0, 0};
+    parallel_mn(bf16_i8_mn, &x, M, N, nthreads);
+}
+
+/* Same, with D tensors addressed as full row-major (M, N) matrices of row stride ldd0 / ldd1 (0 = per column). */
+void wqo_gemm_bf16_i8_dmat(const uint16_t* a, const int8_t* b0, const uint16_t* b1, uint16_t* e, int M,
+                           int N, int K, int lda, int b_sk, int b_sn, int lde, int epilogue,
+                           const uint16_t* d0, int ldd0, const uint16_t* d1, int ldd1, int nthreads)
+{
+    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue, ldd0, ldd1};
     parallel_mn(bf16_i8_mn, &x, M, N, nthreads);
 }
 

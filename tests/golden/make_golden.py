@@ -187,6 +187,29 @@ def gemm_cases(ref) -> dict:
             out["i8_small_a"], out["i8_small_b"], bias_s, M, N, K, 104, 100, 32, 0.25, relu)
         out[f"i8_small_e_relu{relu}"] = ref.gemm_i8_bias_requant(
             out["i8_small_a"], out["i8_small_b"], None, M, N, K, 104, 100, 32, 0.25, relu)
+
+    # ---- example/35's split-K problem: bf16 A x int8 B (row-major (K, N), no scale) -> bf16, the reference's
+    # ReferenceGemm<bhalf, int8, bhalf, float> over the whole K.  Integer set as its init_method 2 draws
+    # (GeneratorTensor_2{-2, 2}: values -2 .. 1), and a decimal set.
+    M, N, K = 64, 128, 512
+    brow = rng.integers(-2, 2, (K, N)).astype(np.int8)
+    a_int = bf16_bits_trunc(rng.integers(-2, 2, (M, K)).astype(np.float32))
+    a_dec = bf16_bits_trunc(rng.uniform(-0.5, 0.5, (M, K)))
+    brow_full = rng.integers(-128, 128, (K, N)).astype(np.int8)
+    out["sk_a_int"], out["sk_a_dec"], out["sk_brow"], out["sk_brow_full"] = a_int, a_dec, brow, brow_full
+    out["sk_c_int"] = ref.gemm_bf16_i8_unscaled(a_int, brow, M, N, K, K, N, 1, N)
+    out["sk_c_dec"] = ref.gemm_bf16_i8_unscaled(a_dec, brow_full, M, N, K, K, N, 1, N)
+
+    # ---- the bf16 x int8 case above with D handed over as a full (M, N) matrix (client_example/30's bias form) ----
+    M, N, K = 48, 64, 128
+    dm0 = bf16_bits_trunc(rng.uniform(0.5, 1.5, (M, N)))
+    dm1 = bf16_bits_trunc(rng.uniform(-0.5, 0.5, (M, N + 8)))      # padded rows: ldd1 = N + 8
+    out["bf16_dm0"], out["bf16_dm1"] = dm0, dm1
+    for ep in (3, 4, 5, 6):
+        out[f"bf16_dmat_e_col_ep{ep}"] = ref.gemm_bf16_i8_dmat(out["bf16_a"], out["bf16_bcol"], out["bf16_s"], M, N, K, K, 1, K,
+                                                               N, ep, dm0, N)
+    out["bf16_dmat_e_col_ep2"] = ref.gemm_bf16_i8_dmat(out["bf16_a"], out["bf16_bcol"], None, M, N, K, K, 1, K, N, 2, dm0, N,
+                                                       dm1, N + 8)
     return out
 
 

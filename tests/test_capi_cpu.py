@@ -162,3 +162,62 @@ def test_product_never_touches_the_checker():
                 if re.search(r"\boracle\b|wq_oracle|libck_ref", text):
                     offenders.append(os.path.relpath(os.path.join(dirpath, f), root))
     assert not offenders, offenders
+
+
+def test_reduce_finalize_validates_epilogue_operands():
+    """wqgemm_reduce_finalize is a public entry point of its own: it must refuse an epilogue whose D vectors are
+    missing, and the int8 requantisation kinds (which have no split-K form), before anything is launched."""
+    fake = 0x10000
+    for epi in (capi.EPI_MULTIPLY_MULTIPLY, capi.EPI_ADD, capi.EPI_MULTIPLY_FASTGELU, capi.EPI_MULTIPLY_ADD_FASTGELU):
+        p = _problem(M=64, N=64, K=64, epilogue=epi, d0=None, d1=None)
+        assert capi.lib.wqgemm_reduce_finalize(C.byref(p), fake, 1, None) == capi.ERR_INVALID
+        assert b"needs d0" in capi.lib.wqgemm_last_error()
+    p = _problem(M=64, N=64, K=64, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=fake, d1=None)
+    assert capi.lib.wqgemm_reduce_finalize(C.byref(p), fake, 1, None) == capi.ERR_INVALID
+    for epi in (capi.EPI_ACT_MUL_CLAMP, capi.EPI_RELU_MUL_CLAMP, capi.EPI_ADD_ACT_MUL_CLAMP, 99):
+        p = _problem(M=64, N=64, K=64, epilogue=epi, d0=fake)
+        assert capi.lib.wqgemm_reduce_finalize(C.byref(p), fake, 1, None) == capi.ERR_UNSUPPORTED
+    p = _problem(M=64, N=64, K=64, epilogue=capi.EPI_ADD, d0=fake, ldd0=-1)
+    assert capi.lib.wqgemm_reduce_finalize(C.byref(p), fake, 1, None) == capi.ERR_INVALID
+
+
+def test_fp8_activations_refuse_a_weight_scale():
+    """The fp8 kernels take their scales through d0 / d1; a weight scale would be dropped, so it is refused."""
+    fake = 0x10000
+    kw = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=fake, d1=fake)
+    assert capi.is_supported(_problem(scale=None, **kw))
+    assert not capi.is_supported(_problem(scale=fake, **kw))
+    assert b"scale must be NULL" in capi.lib.wqgemm_last_error()
+    assert not capi.is_supported(_problem(scale=fake, flags=capi.FLAG_GENERIC, **kw))
+
+
+def test_row_major_weights_with_split_k_route_and_workspace():
+    """Row-major (K, N) int8 weights with the caller's k_batch (example/35's bf16A_i8B problem): matrix-core kernel
+    over a K-contiguous copy that follows the fp32 slabs in the workspace."""
+    M, N, K = 256, 1024, 512
+    kw = dict(M=M, N=N, K=K, a_dtype=capi.BF16, b_dtype=capi.I8, b_layout=capi.ROW_MAJOR, scale=None)
+    for kb in (2, 3, 5, 8):
+        p = _problem(k_batch=kb, **kw)
+        assert capi.is_supported(p)
+        assert capi.kernel_name(p) == "wq_transpose_b8+wq_gemm_mfma_128"
+        assert capi.workspace_bytes(p) == kb * M * N * 4 + K * N
+        assert capi.lib.wqgemm_launch(C.byref(p), None, None) == capi.ERR_WORKSPACE
+    p = _problem(k_batch=1, **kw)
+    assert capi.workspace_bytes(p) == K * N
+    # a K that is not whole 64-deep tiles stays on the general kernel, slabs only
+    p = _problem(k_batch=2, **dict(kw, K=437, lda=437))
+    assert capi.kernel_name(p) == "wq_gemm_generic" and capi.workspace_bytes(p) == 2 * M * N * 4
+
+
+def test_ck_factory_registrations_link():
+    """The factory specialisations this engine adds next to CK's resolve to composable_kernel_amd/ck_instances/ (binary
+    built only where the CK tree is mounted; it constructs the operators and touches no GPU)."""
+    import subprocess
+
+    import pytest
+    exe = os.path.join(ROOT, "examples", "_ref_build", "ck_factory_check")
+    if not os.path.exists(exe):
+        pytest.skip("ck_factory_check not built (needs the CK tree)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "found 8 instances" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("DeviceGemmSplitK_WeightQuant_gfx950") == 4

@@ -69,6 +69,41 @@ def test_reference_example64_source_dropin(init):
     assert "Perf:" in r.stdout and "DeviceFpAintBGemm_Mfma_gfx950" in r.stdout
 
 
+@pytest.mark.parametrize("kbatch", [1, 2, 3, 5, 8])
+def test_reference_example35_splitk_source_dropin(kbatch):
+    """CK's example/35_splitK_gemm/gemm_xdl_splitk_reduce_bf16A_i8B.cpp compiled unmodified over include/dropin
+    (argv: verify init time M N K StrideA StrideB StrideC KBatch; bf16 A, row-major int8 B): the caller sizes and hands
+    over the workspace (GetWorkSpaceSize / SetWorkSpacePointer) and the binary returns 0 only if
+    ck::utils::check_err(device, CK's ReferenceGemm) passed.  KBatch values: the reference's split-K test set
+    (test/gemm_split_k/test_gemm_splitk_util.hpp:36-87)."""
+    r = _run(os.path.join(EX, "_ref_build", "example35_gemm_xdl_splitk_reduce_bf16A_i8B_dropin"),
+             1, 2, 1 if kbatch == 2 else 0, 256, 1024, 512, 512, 1024, 1024, kbatch)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "does not support this problem" not in r.stderr and f"KBatch: {kbatch}" in r.stdout
+    if kbatch == 2:
+        assert "Perf:" in r.stdout and "DeviceGemmV2R1_WeightQuant_gfx950" in r.stdout
+
+
+def test_reference_example35_default_arguments():
+    r = _run(os.path.join(EX, "_ref_build", "example35_gemm_xdl_splitk_reduce_bf16A_i8B_dropin"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Perf:" in r.stdout and "DeviceGemmV2R1_WeightQuant_gfx950" in r.stdout
+
+
+@pytest.mark.parametrize("dtype,layout,kbatch", [(7, 0, 0), (7, 1, 3), (8, 0, 5), (8, 1, 2)])
+def test_reference_profiler_splitk_loop_dropin(dtype, layout, kbatch):
+    """CK's OWN ckProfiler split-K loop (profile_gemm_splitk_impl.hpp, unmodified) instantiated for int8 weights: it
+    finds the gfx950 operator through the factory header this engine adds, sweeps KBatch (0 = CK's list 1 .. 38) and
+    verifies every run against ReferenceGemm with check_err's defaults."""
+    r = _run(os.path.join(EX, "_ref_build", "ck_profile_gemm_splitk_weight_quant_dropin"),
+             "gemm_splitk", dtype, layout, 1, 1, 0, 1, 256, 512, 1024, -1, -1, -1, kbatch)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "found 1 instances" in r.stdout and "Best Perf" in r.stdout
+    assert "DeviceGemmSplitK_WeightQuant_gfx950" in r.stdout and "does not support" not in r.stdout
+    if kbatch == 0:
+        assert r.stdout.count("Perf:") >= 10
+
+
 @pytest.mark.parametrize("fmt,gelu,init", [(0, 0, 1), (1, 0, 1), (1, 1, 2), (2, 0, 1), (2, 1, 2)])
 def test_fp8_int4_multiply_multiply_example(fmt, gelu, init):
     """example/65's flow (fp8 A, D0 per column, D1 per row, host ReferenceGemm + check_err): FNUZ bytes through

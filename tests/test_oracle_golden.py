@@ -220,3 +220,31 @@ def test_splitk_partition_and_reduce(port):
     full = port.fpAintB_gemm_f16(a, b, s, M, N, K, K, K, N)
     # integer-valued inputs: partial sums are exact, so split-K equals the one-pass result bit for bit
     np.testing.assert_array_equal(port.splitk_reduce_f16(parts), full)
+
+
+def test_splitk_unscaled_bf16_i8_cases(port, golden_gemm):
+    """example/35's problem (bf16 A, row-major int8 B, no scale): the port's loop against the reference's
+    ReferenceGemm<bhalf, int8, bhalf, float> outputs, bit for bit."""
+    g = golden_gemm
+    M, N, K = 64, 128, 512
+    got = port.gemm_bf16_i8(g["sk_a_int"], g["sk_brow"], None, M, N, K, K, N, 1, N, 0)
+    np.testing.assert_array_equal(got, g["sk_c_int"])
+    got = port.gemm_bf16_i8(g["sk_a_dec"], g["sk_brow_full"], None, M, N, K, K, N, 1, N, 0)
+    np.testing.assert_array_equal(got, g["sk_c_dec"])
+
+
+def test_bf16_i8_full_matrix_d_cases(port, golden_gemm):
+    """D tensors handed over as full (M, N) matrices (row stride = leading dimension) against the reference's
+    functors applied to d_m_n(m, n)."""
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    for ep in (3, 4, 5, 6):
+        got = port.gemm_bf16_i8_dmat(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, K, 1, K, N, ep, g["bf16_dm0"], N)
+        np.testing.assert_array_equal(got, g[f"bf16_dmat_e_col_ep{ep}"])
+    got = port.gemm_bf16_i8_dmat(g["bf16_a"], g["bf16_bcol"], None, M, N, K, K, 1, K, N, 2, g["bf16_dm0"], N,
+                                 g["bf16_dm1"], N + 8)
+    np.testing.assert_array_equal(got, g["bf16_dmat_e_col_ep2"])
+    # ldd = 0 is the per-column form
+    a = port.gemm_bf16_i8_dmat(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, K, 1, K, N, 3, g["bf16_d0"], 0)
+    b = port.gemm_bf16_i8(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, K, 1, K, N, 3, g["bf16_d0"], g["bf16_d1"])
+    np.testing.assert_array_equal(a, b)
