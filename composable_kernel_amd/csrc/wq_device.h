@@ -236,16 +236,29 @@ struct EpilogueArgs
     int ldd0, ldd1;
 };
 
-// unary_element_wise_operation.hpp:443-452 (host form: true exp and true division, in fp32 here)
+// FastGelu, unary_element_wise_operation.hpp:443-465: u = x (c1 x^2 + c2), y = x / (1 + exp(u)) with
+// c1 = -2 * 0.035677, c2 = -2 * 0.797885.  Evaluated as the reference's device form does (hardware exponential and
+// reciprocal instead of the host's libm exp and true division), with log2(e) folded into the two constants so that the
+// exponential is one v_exp_f32: u' = x fma(c1', x^2, c2'), y = x rcp(1 + exp2(u')).  The scalar and the two-wide
+// forms perform the same IEEE operations, so every kernel and the split-K reduce produce the same bits.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+constexpr float kGeluC1L2E = (float)(-2.0 * 0.035677 * 1.44269504088896341);
+constexpr float kGeluC2L2E = (float)(-2.0 * 0.797885 * 1.44269504088896341);
+
 __device__ __forceinline__ float fast_gelu(float x)
 {
-    const float c1  = (float)(-2.0 * 0.035677f);
-    const float c2  = (float)(-2.0 * 0.797885f);
-    const float u   = x * (c1 * x * x + c2);
-    // the reference's device form (unary_element_wise_operation.hpp:455-465): low-precision exp and rcp;
-    // exp(u) = exp2(u * log2 e) on the transcendental unit (inf for large u gives rcp(inf) = 0 as it should)
-    const float emu = __builtin_amdgcn_exp2f(u * 1.44269504088896341f);
+    const float inner = __builtin_fmaf(kGeluC1L2E, x * x, kGeluC2L2E);
+    const float emu   = __builtin_amdgcn_exp2f(x * inner); // (inf for large arguments gives rcp(inf) = 0 as it should)
     return x * __builtin_amdgcn_rcpf(1.f + emu);
+}
+
+// two outputs per instruction where the ISA has packed fp32 arithmetic (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32)
+__device__ __forceinline__ f2_t fast_gelu2(f2_t x)
+{
+    const f2_t c1 = {kGeluC1L2E, kGeluC1L2E}, c2 = {kGeluC2L2E, kGeluC2L2E}, one = {1.f, 1.f};
+    const f2_t u  = x * __builtin_elementwise_fma(c1, x * x, c2);
+    const f2_t d  = one + f2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+    return x * f2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
 __device__ __forceinline__ float load_d_as_f32(const void* d, int idx, int c_dtype)
@@ -319,21 +332,63 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
         return x;
 }
 
+// The same functors on the four consecutive columns n .. n+3 of row m that one accumulator fragment holds, two
+// columns per instruction.  Operation order per element is that of apply_epilogue_k (identical bits).
+template <int KIND>
+__device__ __forceinline__ f4_t apply_epilogue4(const EpilogueArgs& e, f4_t v, int m, int n)
+{
+    f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    if constexpr(KIND == 2 || (KIND >= 6 && KIND <= 9))
+    {
+        const int i0 = m * e.ldd0 + n;
+        const f2_t d0l = {load_d_as_f32(e.d0, i0, e.c_dtype), load_d_as_f32(e.d0, i0 + 1, e.c_dtype)};
+        const f2_t d0h = {load_d_as_f32(e.d0, i0 + 2, e.c_dtype), load_d_as_f32(e.d0, i0 + 3, e.c_dtype)};
+        if constexpr(KIND == 6 || KIND == 7)
+            lo = lo + d0l, hi = hi + d0h;
+        else
+            lo = lo * d0l, hi = hi * d0h;
+        if constexpr(KIND == 2)
+        {
+            const int i1 = m * e.ldd1 + n;
+            lo = lo + f2_t{load_d_as_f32(e.d1, i1, e.c_dtype), load_d_as_f32(e.d1, i1 + 1, e.c_dtype)};
+            hi = hi + f2_t{load_d_as_f32(e.d1, i1 + 2, e.c_dtype), load_d_as_f32(e.d1, i1 + 3, e.c_dtype)};
+        }
+    }
+    else if constexpr(KIND == 3 || KIND == 4)
+    {
+        const float* d0 = (const float*)e.d0 + (m * e.ldd0 + n);
+        const float* d1 = (const float*)e.d1 + (m + n * e.ldd1);
+        lo = lo * f2_t{d0[0], d0[1]}, hi = hi * f2_t{d0[2], d0[3]};
+        lo = lo * f2_t{d1[0], d1[e.ldd1]}, hi = hi * f2_t{d1[2 * e.ldd1], d1[3 * e.ldd1]};
+    }
+    if constexpr(KIND == 1 || KIND == 2 || KIND == 4 || KIND == 7 || KIND == 9)
+        lo = fast_gelu2(lo), hi = fast_gelu2(hi);
+    return f4_t{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// four fp32 values -> four 16-bit outputs in two registers (fp16: round to nearest even; bf16: truncation)
+template <bool BF16>
+__device__ __forceinline__ u2_t pack_out4(f4_t y)
+{
+    u2_t pk;
+    if constexpr(BF16)
+    {
+        pk[0] = __builtin_amdgcn_perm(as_u32(y[1]), as_u32(y[0]), 0x07060302u);
+        pk[1] = __builtin_amdgcn_perm(as_u32(y[3]), as_u32(y[2]), 0x07060302u);
+    }
+    else
+    {
+        const h2_t a = __builtin_convertvector(f2_t{y[0], y[1]}, h2_t), b = __builtin_convertvector(f2_t{y[2], y[3]}, h2_t);
+        pk[0] = as_u32(a), pk[1] = as_u32(b);
+    }
+    return pk;
+}
+
 // Store one accumulator fragment: lane holds C[m][n .. n+3] (fp32) of a row-major C.
 template <int KIND, bool BF16>
 __device__ __forceinline__ void store_c4(const EpilogueArgs& e, void* c, int ldc, f4_t v, int m, int n)
 {
-    uint16_t o[4];
-#pragma unroll
-    for(int j = 0; j < 4; ++j)
-    {
-        const float y = apply_epilogue_k<KIND>(e, v[j], m, n + j);
-        o[j]          = BF16 ? f32_to_bf16_trunc(y) : __builtin_bit_cast(uint16_t, (_Float16)y);
-    }
-    u2_t pk;
-    pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-    pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-    *(u2_t*)((uint16_t*)c + (size_t)m * ldc + n) = pk;
+    *(u2_t*)((uint16_t*)c + (size_t)m * ldc + n) = pack_out4<BF16>(apply_epilogue4<KIND>(e, v, m, n));
 }
 
 // The requantisation family on an int32 accumulator: kind 5 Activation_Mul_Clamp<PassThrough>, 10 <Relu>,

@@ -1,4 +1,6 @@
-// 256 x 256 x 128 MFMA kernel for fp8 activations x packed int4 weights (gfx950).
+// 256 x 256 x 128 MFMA kernel for fp8 activations x packed int4 weights (gfx950), four-section ping-pong form
+// (wq_gemm_f8_mfma_256_pp; kept for A/B runs and the section-cycle diagnostics -- the product default is the
+// software-pipelined form in wq_gemm_256_f8s.h, which shares the helpers below).
 //
 // Arithmetic: C[m][n] = epilogue( sum_k float(a[m][k]) * float(q[k][n]) ), the per-channel scales of
 // the weights arrive through the epilogue (MultiplyMultiply: d0[n], d1[m]), as in
@@ -98,7 +100,7 @@ __device__ __forceinline__ void dequant8_i4_e5m2(int& o0, int& o1, const I4F8Con
 // (Issuing the LDS-DMA pieces between the MFMAs that carry no conversion work instead of in the load sections
 // was measured 6 % slower: a piece costs an MFMA section 100-130 cycles.)
 template <bool STAMP = false>
-__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p)
+__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256_pp(const GemmParams p)
 {
     using T = Mfma256F8;
     constexpr int MT = 16, NT = 2, MH = MT / 2;

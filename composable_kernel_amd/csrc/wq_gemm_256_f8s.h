@@ -1,0 +1,276 @@
+// 256 x 256 x 128 MFMA kernel for fp8 activations x packed int4 weights (gfx950), software-pipelined form.
+//
+// Same arithmetic, operand formats and epilogue as the ping-pong form wq_gemm_f8_mfma_256_pp (wq_gemm_256_f8.h): E4M3 activation bytes
+// and weights converted in registers to E5M2 feed v_mfma_scale_f32_16x16x128_f8f6f4; FNUZ bytes run with a 2^-1
+// block scale.  What differs is how a wave's loads meet its MFMAs:
+//
+//   * no load sections: every wave streams its own operands between its own MFMAs.  The activation fragments of
+//     row block mt + LEAD are fetched from LDS while row block mt is multiplied (a rolling window of LEAD + 1
+//     fragments, 8 VGPRs each), the weights of the NEXT K tile are converted a piece at a time behind the MFMAs
+//     of the current one, and the global loads of later tiles are issued in the last row blocks of a tile;
+//   * the packed weights never pass through LDS: with the 1 x 8 wave grid each weight is needed by exactly one
+//     wave, so a lane loads the 16 bytes (32 nibbles = its 32 k of one column) of each of its two columns
+//     straight into registers, two K tiles ahead;
+//   * LDS holds only activations: a ring of four 32 KiB slots filled by LDS-DMA three K tiles ahead;
+//   * ONE s_barrier per K tile (not four): barrier(t), in front of row block 12 of tile t, is the point where
+//     tile t+1 is complete for everybody (each wave first waits for its own DMA of tile t+1 with a counted
+//     vmcnt) and where the slot of tile t-1 may be refilled (a wave that reaches it has multiplied most row
+//     blocks of tile t, so its reads of tile t-1 retired long ago).
+// The two waves of a SIMD are symmetric and compete for the matrix pipe instruction by instruction; nothing forces
+// them into phases, so a wave that stalls on a load leaves the pipe to its partner.
+//
+// VMEM bookkeeping (in-order completion, counted waits).  Tile t issues B(t+2) x 2 (registers) in its first row
+// block and A(t+3) x 4 (LDS-DMA) behind barrier(t).  barrier(t) needs A(t+1), issued at the end of tile t-2;
+// issued after it: B(t+1) x 2, A(t+2) x 4, B(t+2) x 2 -> vmcnt(8).  Converting B(t+1) (all through tile t) needs the
+// loads issued a whole tile earlier; behind them when tile t starts: A(t+2) x 4 -> vmcnt(4).
+#pragma once
+
+#include "wq_gemm_256_f8.h"
+
+namespace wq {
+
+struct Mfma256F8S
+{
+    static constexpr int BM = 256, BN = 256, BK = 128, THREADS = 512, NBUF = 4;
+    static constexpr int A_ROW_BYTES = BK;               // 128
+    static constexpr int A_TILE      = BM * A_ROW_BYTES; // 32 KiB
+    static constexpr int RING_BYTES  = NBUF * A_TILE;    // 128 KiB
+    static constexpr int LDS_BYTES   = RING_BYTES > kCTileBytes ? RING_BYTES : kCTileBytes;
+    static constexpr int A_DMA       = A_TILE / 1024 / 8; // LDS-DMA instructions per wave per tile: 4
+    static constexpr int LEAD        = 3;                 // row blocks between a fragment's fetch and its MFMAs (window of 4 divides 16)
+};
+
+__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p)
+{
+    using T = Mfma256F8S;
+    constexpr int MT = 16, NT = 2, LEAD = T::LEAD, WIN = LEAD + 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const int lane  = threadIdx.x & 63;
+    const int wave  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr    = lane & 15;
+    const int fq    = lane >> 4;
+    const int col_w = wave * (NT * 16);
+
+    int tm, tn;
+    {
+        const int nwg = p.tiles_m * p.tiles_n;
+        tile_coords(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    }
+    const int m0 = tm * T::BM, n0 = tn * T::BN;
+
+    const int kz_begin = p.k_begin + blockIdx.z * p.k_per_z;
+    const int kz_end   = min(p.k_end, kz_begin + p.k_per_z);
+    const int ntiles   = (kz_end - kz_begin) / T::BK;
+
+    I4F8Consts i4c;
+    i4c.init();
+    const int scale_w = 0x7F7F7F7F; // weights: 2^0
+    const int scale_a = p.a_scale;  // activations: 2^0 (E4M3FN bytes) or 2^-1 (FNUZ bytes)
+
+    // Activations: buffer resource ending with the last byte of row M - 1 (rows a partial last row tile has past M
+    // are out of range: answered without touching memory, results never stored); a running scalar offset per
+    // DMA piece and one per-lane offset (the source-side swizzle depends on bits 1, 2 of the row only).
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.K), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, 0x7FFFFFFF, 0x00020000);
+    // The tile body always issues the loads of tiles t+2 / t+3 (straight-line code, constant vmcnt arithmetic); past
+    // the last tile they go through a resource of zero records: out of range, answered with zeros, no memory access.
+    const __amdgpu_buffer_rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    uint32_t a_run[T::A_DMA];
+#pragma unroll
+    for(int i = 0; i < T::A_DMA; ++i)
+        a_run[i] = (uint32_t)(m0 + (wave * T::A_DMA + i) * 8) * (uint32_t)p.lda + kz_begin;
+    const uint32_t a_lane = (uint32_t)(lane >> 3) * p.lda + (((lane & 7) ^ f8_a_swz(lane >> 3)) << 4);
+    // Weights: lane (fr, fq) owns bytes [16 fq, 16 fq + 16) of the 64-byte K-tile row of columns col_w + 16 nt + fr
+    uint32_t b_voff[NT];
+#pragma unroll
+    for(int nt = 0; nt < NT; ++nt)
+        b_voff[nt] = (uint32_t)(n0 + col_w + nt * 16 + fr) * (uint32_t)p.ldb_bytes + fq * 16;
+    const uint32_t b_base = kz_begin / 2;
+
+    auto dma_a = [&](const __amdgpu_buffer_rsrc_t& rsrc, int slot, int i) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * T::A_TILE + (wave * T::A_DMA + i) * 1024),
+                                                 16, a_lane, a_run[i], 0, 0);
+        a_run[i] += T::A_ROW_BYTES;
+    };
+    // weights of K tile `tile` (scalar byte offset = the loads' soffset)
+    auto load_b = [&](const __amdgpu_buffer_rsrc_t& rsrc, u4_t(&dst)[NT], int tile) __attribute__((always_inline)) {
+        const uint32_t soff = __builtin_amdgcn_readfirstlane(b_base + (uint32_t)tile * (T::BK / 2));
+#pragma unroll
+        for(int nt = 0; nt < NT; ++nt)
+            dst[nt] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b_voff[nt], soff, 0));
+    };
+
+    f4_t acc[NT][MT];
+#pragma unroll
+    for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for(int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    // this lane's two 16-byte chunks of row fr of row block 0 (swizzled position inside the 128-byte row)
+    int a_off[2];
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+        a_off[h] = fr * 128 + (((2 * fq + h) ^ f8_a_swz(fr)) << 4);
+
+    i8v_t af[WIN];     // rolling window of activation fragments
+    u4_t raw[2][NT];   // packed weights of tiles t+1 / t+2 (by tile parity)
+    i8v_t wf[2][NT];   // converted weights of tiles t / t+1 (by tile parity)
+
+    auto read_a = [&](int slot, int mt, auto win) __attribute__((always_inline)) {
+        constexpr int w   = decltype(win)::value;
+        const uint8_t* sa = lds + slot * T::A_TILE + mt * 16 * 128;
+        const u4_t lo     = *(const u4_t*)(sa + a_off[0]);
+        const u4_t hi     = *(const u4_t*)(sa + a_off[1]);
+        af[w][0] = lo[0], af[w][1] = lo[1], af[w][2] = lo[2], af[w][3] = lo[3];
+        af[w][4] = hi[0], af[w][5] = hi[1], af[w][6] = hi[2], af[w][7] = hi[3];
+    };
+    // conversion piece j (0..7) = 32-bit word j % 4 of raw[.][j / 4] -> registers 2 (j % 4), +1 of out[j / 4]
+    auto convert_piece = [&](i8v_t(&out)[NT], const u4_t(&in)[NT], auto piece) __attribute__((always_inline)) {
+        constexpr int j = decltype(piece)::value, nt = j / 4, d = j % 4;
+        int o0, o1;
+        dequant8_i4_e5m2(o0, o1, i4c, in[nt][d]);
+        out[nt][2 * d]     = o0;
+        out[nt][2 * d + 1] = o1;
+        asm volatile("" : "+v"(out[nt][2 * d]), "+v"(out[nt][2 * d + 1]));
+    };
+
+    // half a conversion piece: half h (0 / 1) of 32-bit word d of raw[.][nt] -> register 2 d + h of out[nt] (4 weights,
+    // 5 or 6 VALU instructions)
+    auto convert_half = [&](i8v_t(&out)[NT], const u4_t(&in)[NT], auto idx) __attribute__((always_inline)) {
+        constexpr int j = decltype(idx)::value, nt = j / 8, d = (j % 8) / 2, h = j % 2;
+        const uint32_t w = h ? in[nt][d] >> 8 : in[nt][d];
+        const h2_t t0    = as_h2(and_or_s(w, i4c.mask_lo, i4c.magic)) - i4c.k1032;
+        const h2_t t1    = __builtin_elementwise_fma(as_h2(and_or_s(w, i4c.mask_hi, i4c.magic)), i4c.k16th, i4c.km72);
+        out[nt][2 * d + h] = (int)__builtin_amdgcn_perm(as_u32(t1), as_u32(t0), 0x07050301u);
+        asm volatile("" : "+v"(out[nt][2 * d + h]));
+    };
+
+    if(ntiles <= 0)
+    {
+        tile256_epilogue<NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
+        return;
+    }
+
+    // ---- prologue: A(0), B(0), A(1), B(1), A(2); tile 0 complete and converted, first LEAD fragments fetched ----
+#pragma unroll
+    for(int i = 0; i < T::A_DMA; ++i)
+        dma_a(a_rsrc, 0, i);
+    load_b(b_rsrc, raw[0], 0);
+    {
+        const __amdgpu_buffer_rsrc_t a1 = ntiles > 1 ? a_rsrc : null_rsrc, b1 = ntiles > 1 ? b_rsrc : null_rsrc;
+        const __amdgpu_buffer_rsrc_t a2 = ntiles > 2 ? a_rsrc : null_rsrc;
+#pragma unroll
+        for(int i = 0; i < T::A_DMA; ++i)
+            dma_a(a1, 1, i);
+        load_b(b1, raw[1], 1);
+#pragma unroll
+        for(int i = 0; i < T::A_DMA; ++i)
+            dma_a(a2, 2, i);
+    }
+    wait_vmcnt<2 * T::A_DMA + 2>(); // A(0), B(0) done
+    __builtin_amdgcn_s_barrier();
+    {
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 0>{});
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 1>{});
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 2>{});
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 3>{});
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 4>{});
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 5>{});
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 6>{});
+        convert_piece(wf[0], raw[0], std::integral_constant<int, 7>{});
+    }
+    read_a(0, 0, std::integral_constant<int, 0>{});
+    read_a(0, 1, std::integral_constant<int, 1>{});
+    read_a(0, 2, std::integral_constant<int, 2>{});
+    static_assert(LEAD == 3, "prologue fetches LEAD fragments");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- one K tile; PAR = t & 1 selects the register sets at compile time.  Straight-line: loads of tiles past the
+    // last one are issued through the null resource, the reads and the conversion for a tile that does not exist
+    // work on stale bytes whose results are never used. ----
+    int slot = 0; // ring slot of tile t
+    int t    = 0;
+    auto tile_body = [&](auto par) __attribute__((always_inline)) {
+        constexpr int P = decltype(par)::value, Q = 1 - P;
+        const int slot1 = (slot + 1) & 3, slot3 = (slot + 3) & 3;
+        const __amdgpu_buffer_rsrc_t b2 = t + 2 < ntiles ? b_rsrc : null_rsrc;
+        const __amdgpu_buffer_rsrc_t a3 = t + 3 < ntiles ? a_rsrc : null_rsrc;
+
+        auto row_block = [&](auto mt_c) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mt_c)::value;
+            constexpr int w  = mt % WIN;          // window entry multiplied now
+            constexpr int wn = (mt + LEAD) % WIN; // window entry fetched now
+            if constexpr(mt == MT - LEAD)
+            {
+                // barrier(t): tile t+1 complete for everybody, slot of tile t-1 free
+                wait_vmcnt<T::A_DMA + 4>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // fetch the fragment LEAD row blocks ahead (of this tile, or the first ones of the next)
+            if constexpr(mt + LEAD < MT)
+                read_a(slot, mt + LEAD, std::integral_constant<int, wn>{});
+            else
+                read_a(slot1, mt + LEAD - MT, std::integral_constant<int, wn>{});
+            // global loads of later tiles: weights at once (no LDS hazard), activations behind barrier(t)
+            if constexpr(mt == 0)
+                wait_vmcnt<T::A_DMA>(); // B(t+1) has landed (issued a tile ago); behind it: A(t+2) x 4
+            if constexpr(mt == 0)
+                load_b(b2, raw[P], t + 2); // B(t+2): raw[P] held tile t's weights, converted during tile t-1
+            if constexpr(mt >= MT - LEAD)
+            {
+                dma_a(a3, slot3, mt - (MT - LEAD));
+                if constexpr(mt == MT - 1)
+                    dma_a(a3, slot3, T::A_DMA - 1);
+            }
+            acc[0][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], acc[0][mt], 1 /* E5M2 */, 0 /* E4M3 */,
+                                                                           0, scale_w, 0, scale_a);
+            acc[1][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], acc[1][mt], 1, 0, 0, scale_w, 0, scale_a);
+            // weights of tile t+1: half a piece (4 weights) per row block, its VALU work behind the two MFMAs
+            convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // the two fragment reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        row_block(std::integral_constant<int, 0>{});
+        row_block(std::integral_constant<int, 1>{});
+        row_block(std::integral_constant<int, 2>{});
+        row_block(std::integral_constant<int, 3>{});
+        row_block(std::integral_constant<int, 4>{});
+        row_block(std::integral_constant<int, 5>{});
+        row_block(std::integral_constant<int, 6>{});
+        row_block(std::integral_constant<int, 7>{});
+        row_block(std::integral_constant<int, 8>{});
+        row_block(std::integral_constant<int, 9>{});
+        row_block(std::integral_constant<int, 10>{});
+        row_block(std::integral_constant<int, 11>{});
+        row_block(std::integral_constant<int, 12>{});
+        row_block(std::integral_constant<int, 13>{});
+        row_block(std::integral_constant<int, 14>{});
+        row_block(std::integral_constant<int, 15>{});
+        slot = slot1;
+        ++t;
+    };
+    static_assert(MT % WIN == 0, "the window entry of a row block must not depend on the tile");
+    for(;;)
+    {
+        tile_body(std::integral_constant<int, 0>{});
+        if(t == ntiles)
+            break;
+        tile_body(std::integral_constant<int, 1>{});
+        if(t == ntiles)
+            break;
+    }
+    wait_vmcnt<0>(); // (null-resource loads of tiles past the end still count)
+
+    __syncthreads(); // every wave is done with the ring before it becomes the C tile image
+    tile256_epilogue<NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
+}
+
+} // namespace wq

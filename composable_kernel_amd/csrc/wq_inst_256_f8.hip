@@ -3,28 +3,26 @@
 
 #include "wqgemm.h"
 #include "wq_gemm_256_f8.h"
+#include "wq_gemm_256_f8s.h"
 
 namespace wq {
 
 namespace {
 
-template <bool STAMP>
-int launch_v(const GemmParams& gp, dim3 grid, hipStream_t s)
+// more than 64 KiB of dynamic LDS must be opted into once per device
+template <typename K>
+int launch_big_lds(K kernel, int lds_bytes, bool (&opted_in)[64], const GemmParams& gp, dim3 grid, hipStream_t s)
 {
-    // more than 64 KiB of dynamic LDS must be opted into once per device
-    static bool opted_in[64] = {};
-    int dev                  = 0;
+    int dev = 0;
     if(hipGetDevice(&dev) != hipSuccess)
         return WQ_ERR_HIP;
-    constexpr int lds_bytes = Mfma256F8::LDS_BYTES;
     if(dev >= 0 && dev < 64 && !opted_in[dev])
     {
-        if(hipFuncSetAttribute((const void*)wq_gemm_f8_mfma_256<STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               lds_bytes) != hipSuccess)
+        if(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return WQ_ERR_HIP;
         opted_in[dev] = true;
     }
-    hipLaunchKernelGGL((wq_gemm_f8_mfma_256<STAMP>), grid, dim3(512), lds_bytes, s, gp);
+    hipLaunchKernelGGL(kernel, grid, dim3(512), lds_bytes, s, gp);
     return WQ_OK;
 }
 
@@ -32,10 +30,12 @@ int launch_v(const GemmParams& gp, dim3 grid, hipStream_t s)
 
 int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant)
 {
-    (void)variant;
-    if(gp.dbg)
-        return launch_v<true>(gp, grid, s);
-    return launch_v<false>(gp, grid, s);
+    static bool opted_s[64] = {}, opted_pp[64] = {}, opted_stamp[64] = {};
+    if(gp.dbg) // diagnostic: the stamped build of the ping-pong form
+        return launch_big_lds(wq_gemm_f8_mfma_256_pp<true>, Mfma256F8::LDS_BYTES, opted_stamp, gp, grid, s);
+    if(variant & WQ_FLAG_F8_PINGPONG)
+        return launch_big_lds(wq_gemm_f8_mfma_256_pp<false>, Mfma256F8::LDS_BYTES, opted_pp, gp, grid, s);
+    return launch_big_lds(wq_gemm_f8_mfma_256, Mfma256F8S::LDS_BYTES, opted_s, gp, grid, s);
 }
 
 } // namespace wq

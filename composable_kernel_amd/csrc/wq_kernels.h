@@ -155,16 +155,7 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
                 const int mt = ph * MTP + mi;
                 const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
                 const int m = min(m0 + r, p.M - 1); // rows of a partial last tile past M: keep per-row operand reads in range
-                uint16_t o[4];
-#pragma unroll
-                for(int j = 0; j < 4; ++j)
-                {
-                    const float y = apply_epilogue_k<KIND>(p.epi, acc[nt][mt][j], m, n0 + c + j);
-                    o[j]          = BF16 ? f32_to_bf16_trunc(y) : __builtin_bit_cast(uint16_t, (_Float16)y);
-                }
-                u2_t pk;
-                pk[0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-                pk[1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                const u2_t pk = pack_out4<BF16>(apply_epilogue4<KIND>(p.epi, acc[nt][mt], m, n0 + c));
                 *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
             }
         __syncthreads();
