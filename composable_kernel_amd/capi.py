@@ -40,7 +40,7 @@ EXPORTS = (
     "wqgemm_version", "wqgemm_last_error", "wqgemm_is_supported", "wqgemm_workspace_bytes",
     "wqgemm_launch", "wqgemm_run_timed", "wqgemm_type_string", "wqgemm_kernel_name",
     "wqgemm_pack_int4", "wqgemm_pack_int4_host", "wqgemm_reduce_finalize", "wqgemm_splitk_kread",
-    "wqgemm_run_timed_rotating",
+    "wqgemm_run_timed_rotating", "wqgemm_launch_noalloc",
 )
 
 
@@ -80,6 +80,8 @@ def _load() -> C.CDLL:
     L.wqgemm_workspace_bytes.argtypes = [P]
     L.wqgemm_launch.restype = C.c_int
     L.wqgemm_launch.argtypes = [P, C.c_void_p, C.c_void_p]
+    L.wqgemm_launch_noalloc.restype = C.c_int
+    L.wqgemm_launch_noalloc.argtypes = [P, C.c_void_p]
     L.wqgemm_run_timed.restype = C.c_int
     L.wqgemm_run_timed.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.wqgemm_run_timed_rotating.restype = C.c_int
@@ -121,6 +123,14 @@ def workspace_bytes(p: Problem) -> int:
 
 def launch(p: Problem, workspace: int | None = None, stream: int | None = None) -> None:
     check(lib.wqgemm_launch(C.byref(p), workspace, stream))
+
+
+NOALLOC_SCRATCH_BYTES = 64 << 20
+
+
+def launch_noalloc(p: Problem, stream: int | None = None) -> None:
+    """wqgemm_launch with the library's built-in per-GPU scratch in place of a caller workspace."""
+    check(lib.wqgemm_launch_noalloc(C.byref(p), stream))
 
 
 def run_timed(p: Problem, workspace: int | None, stream: int | None, cold: int, repeat: int) -> float:

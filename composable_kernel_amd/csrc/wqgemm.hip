@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +25,11 @@ int launch_256_w32(const GemmParams& gp, dim3 grid, hipStream_t s, int ak);    /
 int launch_skinny(int ak, int bk, const GemmParams& gp, dim3 grid, hipStream_t s, int nmb, int p); // wq_inst_skinny.hip
 int launch_skinny_ws(int ak, int bk, const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s, int p);
 } // namespace wq
+
+// Scratch of wqgemm_launch_noalloc: lives in the code object, so every GPU the library's kernels are loaded on holds
+// its own copy, at its own address, until the process ends.  `scratch` itself is only a host-side handle for
+// hipGetSymbolAddress; the kernels receive the address that call returns.
+static __device__ __align__(256) unsigned char scratch[WQGEMM_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -690,6 +696,48 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     if(plan.partial && !plan.to_c)
         return launch_reduce(p, (const float*)workspace, plan.k_batch, s);
     return WQ_OK;
+}
+
+// Device address of this GPU's copy of `scratch`, looked up once per device with that device current.
+static int noalloc_scratch(void** out)
+{
+    static std::atomic<void*> per_device[64];
+    int dev = 0;
+    WQ_HIP(hipGetDevice(&dev));
+    if(dev < 0 || dev >= 64)
+        return fail(WQ_ERR_HIP, "device ordinal %d outside the table of 64", dev);
+    void* ptr = per_device[dev].load(std::memory_order_acquire);
+    if(!ptr)
+    {
+        // (two threads racing here both get the same answer for the same device)
+        WQ_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if(!ptr)
+            return fail(WQ_ERR_HIP, "hipGetSymbolAddress returned a null scratch address");
+        per_device[dev].store(ptr, std::memory_order_release);
+    }
+    *out = ptr;
+    return WQ_OK;
+}
+
+int wqgemm_launch_noalloc(const wqgemm_problem* p, void* stream)
+{
+    Plan plan;
+    if(const int rc = make_plan(p, plan); rc != WQ_OK)
+        return rc;
+    const size_t need = wqgemm_workspace_bytes(p);
+    if(need > WQGEMM_NOALLOC_SCRATCH_BYTES)
+    {
+        if(plan.partial && !plan.auto_split)
+            return fail(WQ_ERR_WORKSPACE, "launch_noalloc: the problem needs %zu bytes of scratch, the built-in scratch holds %u",
+                        need, WQGEMM_NOALLOC_SCRATCH_BYTES);
+        // an optional scratch use (planner split-K, operand re-layout) that does not fit is dropped, as with no workspace
+        return wqgemm_launch(p, nullptr, stream);
+    }
+    void* ws = nullptr;
+    if(need != 0)
+        if(const int rc = noalloc_scratch(&ws); rc != WQ_OK)
+            return rc;
+    return wqgemm_launch(p, ws, stream);
 }
 
 int wqgemm_run_timed(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters,

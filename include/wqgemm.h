@@ -154,6 +154,19 @@ size_t wqgemm_workspace_bytes(const wqgemm_problem* p);
  * (impl/device_fpAintB_gemm_wmma.hpp:424-493; include/ck/host_utility/kernel_launch.hpp:71-77). */
 int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream);
 
+/* wqgemm_launch for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): no workspace argument -- what wqgemm_launch would take from the caller's
+ * workspace (split-K slabs, the fp16 image of FNUZ activations, the K-contiguous copy of row-major weights) comes
+ * from a scratch array built into the library, WQGEMM_NOALLOC_SCRATCH_BYTES (64 MiB) per GPU, resident on every GPU the
+ * library runs on until the process ends.  No counterpart in the reference.  Calls hipMalloc / hipFree never.
+ * A problem with k_batch > 1 whose wqgemm_workspace_bytes exceeds the scratch returns WQ_ERR_WORKSPACE with a message
+ * and launches nothing; an OPTIONAL workspace use that does not fit is dropped exactly as wqgemm_launch drops it
+ * for a NULL workspace.  Results are those of wqgemm_launch with a workspace, bit for bit.  All calls on one GPU
+ * share that GPU's scratch: nothing in it needs initialising (each launch writes every byte it later reads), but two
+ * calls that overlap on one GPU -- different streams or threads -- race on it; serialise them. */
+#define WQGEMM_NOALLOC_SCRATCH_BYTES (64u << 20)
+int wqgemm_launch_noalloc(const wqgemm_problem* p, void* stream);
+
 /* cold_iters untimed launches, then nrepeat launches between one pair of HIP events on
  * `stream`; *avg_ms receives the mean.  Synchronises the stream.  Replaces Invoker::Run with
  * time_kernel == true (include/ck/host_utility/kernel_launch.hpp:20-70;
