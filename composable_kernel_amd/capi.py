@@ -29,7 +29,7 @@ ROW_MAJOR, COL_MAJOR = 0, 1
 FLAG_TILE_128, FLAG_TILE_256, FLAG_LOCKSTEP, FLAG_WAVES_2X4 = 1, 2, 4, 8
 FLAG_DIRECT_STORE, FLAG_GROUP8, FLAG_DEQUANT_IN_L, FLAG_GENERIC, FLAG_F8_NO_SPECIALS = 32, 64, 512, 1024, 2048
 FLAG_MFMA_32X32 = 4096
-FLAG_F8_PINGPONG = 8192
+FLAG_PINGPONG = 8192
 # wq_epilogue
 (EPI_PASSTHROUGH, EPI_FASTGELU, EPI_MULTIPLY_ADD_FASTGELU, EPI_MULTIPLY_MULTIPLY,
  EPI_MULTIPLY_MULTIPLY_FASTGELU, EPI_ACT_MUL_CLAMP, EPI_ADD, EPI_ADD_FASTGELU, EPI_MULTIPLY,

@@ -33,7 +33,7 @@ int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant)
     static bool opted_s[64] = {}, opted_pp[64] = {}, opted_stamp[64] = {};
     if(gp.dbg) // diagnostic: the stamped build of the ping-pong form
         return launch_big_lds(wq_gemm_f8_mfma_256_pp<true>, Mfma256F8::LDS_BYTES, opted_stamp, gp, grid, s);
-    if(variant & WQ_FLAG_F8_PINGPONG)
+    if(variant & WQ_FLAG_PINGPONG)
         return launch_big_lds(wq_gemm_f8_mfma_256_pp<false>, Mfma256F8::LDS_BYTES, opted_pp, gp, grid, s);
     return launch_big_lds(wq_gemm_f8_mfma_256, Mfma256F8S::LDS_BYTES, opted_s, gp, grid, s);
 }

@@ -121,7 +121,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_INVALID, "M, N, K must be positive (got %d, %d, %d)", p->M, p->N, p->K);
     if(!p->a || !p->b || !p->c)
         return fail(WQ_ERR_INVALID, "a, b and c must be non-null device pointers");
-    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_GENERIC | WQ_FLAG_F8_NO_SPECIALS | WQ_FLAG_MFMA_32X32 | WQ_FLAG_F8_PINGPONG))
+    if(p->flags & ~(WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256 | WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DIRECT_STORE | WQ_FLAG_GROUP8 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_GENERIC | WQ_FLAG_F8_NO_SPECIALS | WQ_FLAG_MFMA_32X32 | WQ_FLAG_PINGPONG))
         return fail(WQ_ERR_INVALID, "unknown bits in flags");
     if(p->c_layout != WQ_ROW_MAJOR)
         return fail(WQ_ERR_UNSUPPORTED, "only row-major C is implemented");

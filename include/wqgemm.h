@@ -79,7 +79,7 @@ typedef enum wq_epilogue
 #define WQ_FLAG_GENERIC 1024     /* force the generic (one thread per output) kernel */
 #define WQ_FLAG_F8_NO_SPECIALS 2048 /* WQ_F8_FNUZ activations hold none of the bytes 0x7F, 0xFF (+-240) and 0x80 (NaN): allows the fp8 matrix-core kernel, which reads FNUZ bytes as E4M3FN / 2 and cannot express those three */
 #define WQ_FLAG_MFMA_32X32 4096 /* 256-tile kernel built on v_mfma_f32_32x32x16 (packed int4 weights; tuning A/B) */
-#define WQ_FLAG_F8_PINGPONG 8192 /* fp8 x int4 kernel in its four-section ping-pong form instead of the software-pipelined default (tuning A/B) */
+#define WQ_FLAG_PINGPONG 8192 /* fp8 x int4 kernel in its four-section ping-pong form instead of the software-pipelined default (tuning A/B) */
 #define WQ_FLAG_GROUP8 64       /* walk tiles in groups of 8 tile rows instead of the cost-minimising group (tuning A/B) */
 
 /* One GEMM problem: C[M,N] = epilogue( sum_k A[m,k] * dequant(B[k,n], scale[n]) ).
