@@ -101,18 +101,21 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed counter summary (separate rocprofv3 --pmc passes for
     FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as gfx950 requires; tools/pmc_summary.py), or None when the
     summary is absent or belongs to another kernel.  Counters cannot be collected from inside this process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_mfma256_pmc.json")
-    try:
-        with open(path) as fh:
-            summary = json.load(fh)
-    except OSError:
-        return None
-    if not any(kernel in k for k in summary.get("kernel", [])):
-        return None
-    return summary.get("hbm_bytes_per_launch")
+    for name in PMC_SUMMARIES:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as fh:
+                summary = json.load(fh)
+        except OSError:
+            continue
+        if any(kernel in k for k in summary.get("kernel", [])) and summary.get("hbm_bytes_per_launch"):
+            return summary["hbm_bytes_per_launch"], (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                                     "earlier run of this kernel on this shape, not measured by this process")
+    return None, None
 
 
 PEAK_8BIT_MFMA_TFLOPS = 5000.0  # dense fp8 / int8 MFMA peak of MI355X
+PMC_SUMMARIES = ("r2_mfma256_pmc.json", "r1_mfma256_pmc.json")  # newest first
 
 
 def _cpu_cores():
@@ -298,6 +301,11 @@ def workload_c5(dev):
 
 
 WORKLOADS = {"C1": workload_c1, "C2": workload_c2, "C3": workload_c3, "C5": workload_c5}
+HEADLINE_METRIC = "TFLOPs + achieved HBM GB/s, fp16A x int4B GEMM at Llama-7B shapes, 1 GPU"
+METRICS = {"C2": HEADLINE_METRIC,
+           "C1": "TOPs + achieved HBM GB/s, int8 x int8 requantised GEMM 256^3 (BASELINE config 1), 1 GPU",
+           "C3": "TFLOPs + achieved HBM GB/s, bf16A x int8B GEMM at the Llama-7B FFN shape (BASELINE config 3), 1 GPU",
+           "C5": "TFLOPs + achieved HBM GB/s, fp8A x int4B GEMM + MultiplyMultiply + FastGelu (BASELINE config 5), 1 GPU"}
 
 
 def run_single(args):
@@ -325,8 +333,9 @@ def run_single(args):
     tflops = flops * args.steps / wall / 1e12
     kern_tflops = flops / (kern_ms * 1e-3) / 1e12
     nbytes = w["bytes"]
+    traffic, traffic_source = pmc_traffic(capi.kernel_name(p)) if args.config == "C2" else (None, None)
     out = {
-        "metric": "TFLOPs + achieved HBM GB/s, fp16A x int4B GEMM at Llama-7B shapes, 1 GPU",
+        "metric": METRICS[args.config],
         "value": tflops,
         "unit": "TFLOP/s",
         "n_gpus": 1,
@@ -345,7 +354,7 @@ def run_single(args):
         "hbm_frac_of_peak": nbytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
         "roofline": {"bound": "mfma", "achieved": kern_tflops, "peak": w["peak"],
                      "unit": "TFLOP/s", "frac": kern_tflops / w["peak"],
-                     "traffic": pmc_traffic(capi.kernel_name(p)) if args.config == "C2" else None,
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": kern_ms,
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes},
     }
@@ -374,6 +383,24 @@ def run_single(args):
     rot_ms = e0.elapsed_time(e1) / 100
     out["rotating_buffers"] = {"copies": 4, "kernel_ms": rot_ms, "tflops": flops / (rot_ms * 1e-3) / 1e12}
     del copies, probs
+    if args.config == "C2":
+        # Secondary figure, never `value`: the same GEMM with the per-channel scale applied once in the epilogue
+        # (scale = NULL, WQ_EPI_MULTIPLY with d0 = scale) instead of per weight in the loop.  It rounds differently from
+        # the reference (which rounds half(q) * scale per weight: reference_fpAintB_gemm.hpp:110) -- more accurately,
+        # within check_err's tolerance -- so it is the caller's choice, not the measured configuration.
+        a_, q_, s_, bp_, c_ = w["keep"]
+        pf = capi.fpAintB_problem(a_.data_ptr(), bp_.data_ptr(), None, c_.data_ptr(), M, N, K, epilogue=capi.EPI_MULTIPLY,
+                                  d0=s_.data_ptr())
+        for _ in range(50):
+            capi.launch(pf, None, sp)
+        e0.record(stream)
+        for _ in range(100):
+            capi.launch(pf, None, sp)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        out["fast_mode_tflops"] = flops / (e0.elapsed_time(e1) / 100 * 1e-3) / 1e12
+        capi.launch(p, None, sp)  # leave C as the measured configuration computes it (the CPU leg compares it)
+        torch.cuda.synchronize()
     if not args.no_cpu:
         out["cpu_baseline"] = w["cpu"](args.cpu_budget)
     print(json.dumps(out))
@@ -396,25 +423,68 @@ def run_splitk(args):
     dist.broadcast(s, src=0)  # the per-channel scales are replicated
     partial = torch.empty((M, N), dtype=torch.float32, device=dev)
     rows = M // world
-    c_rows = torch.empty((rows, N), dtype=torch.float16, device=dev)
     c_full = torch.empty((M, N), dtype=torch.float16, device=dev)
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
-    p_gemm = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), s.data_ptr(), partial.data_ptr(), M, N, klen,
-                                  k_begin=0, k_end=klen, c_dtype=capi.F32)
-    assert capi.is_supported(p_gemm), capi.lib.wqgemm_last_error().decode()
 
-    def compute_partial(_sl, _partial):
-        capi.launch(p_gemm, None, sp)
+    def slice_problem(a_t, s_t):
+        pg = capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), partial.data_ptr(), M, N, max(klen, 64),
+                                  k_begin=0, k_end=max(klen, 64), c_dtype=capi.F32)
+        assert klen == 0 or capi.is_supported(pg), capi.lib.wqgemm_last_error().decode()
+        return pg
+
+    p_gemm = slice_problem(a, s)
+    cur = {"gemm": p_gemm, "scale": s}
+
+    def compute_partial(sl, partial_):
+        if sl.length == 0:
+            partial_.zero_()  # a rank without a slice contributes zeros
+        else:
+            capi.launch(cur["gemm"], None, sp)
 
     def finalize(summed, out_rows, row0):
-        pf = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), s.data_ptr(), out_rows.data_ptr(),
-                                  summed.shape[0], N, klen)
+        pf = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), cur["scale"].data_ptr(), out_rows.data_ptr(),
+                                  summed.shape[0], N, max(klen, 64))
         capi.reduce_finalize(pf, summed.data_ptr(), 1, sp)
 
     def step():
-        splitk.splitk_step(compute_partial, finalize, partial, c_rows, K, "reduce_scatter")
-        dist.all_gather_into_tensor(c_full, c_rows)
+        splitk.splitk_gemm_step(compute_partial, finalize, partial, c_full, K)
+
+    # ---- untimed check of the whole flow on exact (integer-valued) inputs: rank 0 recomputes a block of C from the
+    # operands of every rank in float64 and compares bit for bit (all partial sums are exact in fp32).
+    check = None
+    if klen > 0 and all(sl_.length == klen for sl_ in splitk.partition(K, world)):
+        g = torch.Generator(device=dev)
+        g.manual_seed(777 + rank)
+        a_int = torch.randint(-2, 3, (M, klen), generator=g, device=dev, dtype=torch.int8).to(torch.float16)
+        s_int = torch.randint(1, 3, (N,), generator=torch.Generator(device=dev).manual_seed(5), device=dev,
+                              dtype=torch.int8).to(torch.float16)
+        cur["gemm"], cur["scale"] = slice_problem(a_int, s_int), s_int
+        step()
+        torch.cuda.synchronize()
+        R, C = 8, 64
+        a_blk = torch.empty((world, R, klen), dtype=torch.float16, device=dev)
+        q_blk = torch.empty((world, C, klen), dtype=torch.int8, device=dev)
+        if world > 1:
+            dist.all_gather_into_tensor(a_blk, a_int[:R].contiguous())
+            dist.all_gather_into_tensor(q_blk, q[:C].contiguous())
+        else:
+            a_blk[0], q_blk[0] = a_int[:R], q[:C]
+        if rank == 0:
+            exp = torch.zeros((R, C), dtype=torch.float64)
+            for r in range(world):
+                exp += a_blk[r].cpu().double() @ (q_blk[r].cpu().double() * s_int[:C].cpu().double()[:, None]).T
+            got = c_full[:R, :C].cpu()
+            check = {"rows": R, "cols": C, "exact_match": bool(torch.equal(got, exp.to(torch.float16))),
+                     "max_abs": float(exp.abs().max())}
+        # (every rank holds the same C after the all-gather: compare rank 0's copy with the last rank's)
+        probe_c = c_full[M - 1, :C].clone()
+        if world > 1:
+            dist.broadcast(probe_c, src=world - 1)
+        if rank == 0:
+            check["ranks_agree"] = bool(torch.equal(probe_c, c_full[M - 1, :C]))
+        cur["gemm"], cur["scale"] = p_gemm, s
+        del a_int, a_blk, q_blk
 
     for _ in range(args.warmup):
         step()
@@ -450,11 +520,11 @@ def run_splitk(args):
         ev[0].record(stream)
         capi.launch(p_gemm, None, sp)
         ev[1].record(stream)
-        summed = splitk.reduce_partials(partial, "reduce_scatter")
+        summed = splitk.reduce_partials(partial, "reduce_scatter") if world > 1 else partial
         ev[2].record(stream)
-        finalize(summed, c_rows, rank * rows)
+        finalize(summed, c_full[rank * rows:(rank + 1) * rows], rank * rows)
         ev[3].record(stream)
-        dist.all_gather_into_tensor(c_full, c_rows)
+        splitk.gather_rows(c_full, rows)
         ev[4].record(stream)
         torch.cuda.synchronize()
         acc += np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
@@ -467,7 +537,7 @@ def run_splitk(args):
         flops_rank = 2.0 * M * N * klen
         kern_tflops = flops_rank / (gemm_ms * 1e-3) / 1e12
         out = {
-            "metric": "TFLOPs + achieved HBM GB/s, fp16A x int4B GEMM at Llama-7B shapes, 1 GPU",
+            "metric": HEADLINE_METRIC,
             "value": flops_total * args.steps / wall / 1e12,
             "unit": "TFLOP/s",
             "n_gpus": world,
@@ -484,11 +554,12 @@ def run_splitk(args):
                                    "fp32 partials, RCCL reduce-scatter + fp16 all-gather (BASELINE config 4)",
                        "M": M, "N": N, "K": K, "k_per_gpu": klen, "parallelism": f"splitk{world}",
                        "kernel": capi.kernel_name(p_gemm)},
+            "splitk_check": check,
             "breakdown_ms": {"gemm": gemm_ms, "reduce_scatter_fp32": reduce_ms, "finalize": fin_ms,
                              "all_gather_fp16": gather_ms},
             "roofline": {"bound": "mfma", "achieved": kern_tflops, "peak": PEAK_FP16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": kern_tflops / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
-                         "kernel_ms": gemm_ms, "algorithmic_flops_per_launch": flops_rank,
+                         "traffic_source": None, "kernel_ms": gemm_ms, "algorithmic_flops_per_launch": flops_rank,
                          "algorithmic_bytes_per_launch": algorithmic_bytes(M, N, klen, c_bytes=4)},
         }
         print(json.dumps(out))

@@ -67,7 +67,13 @@ def reduce_partials(partial: torch.Tensor, strategy: str = "auto", group=None) -
     if strategy == "reduce_scatter":
         M = partial.shape[0]
         assert M % world == 0, "reduce_scatter needs M divisible by the world size"
-        out = torch.empty((M // world,) + tuple(partial.shape[1:]), dtype=partial.dtype, device=partial.device)
+        rows = M // world
+        if backend != "nccl":
+            # gloo has no reduce-scatter: sum everywhere, keep this rank's rows (same result, CPU test path only)
+            dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+            r = dist.get_rank(group)
+            return partial[r * rows:(r + 1) * rows].clone()
+        out = torch.empty((rows,) + tuple(partial.shape[1:]), dtype=partial.dtype, device=partial.device)
         dist.reduce_scatter_tensor(out, partial, op=dist.ReduceOp.SUM, group=group)
         return out
     raise ValueError(f"unknown strategy {strategy!r}")
@@ -98,3 +104,45 @@ def splitk_step(compute_partial: Callable[[KSlice, torch.Tensor], None],
         return
     row0 = 0 if summed.shape[0] == partial.shape[0] else rank * summed.shape[0]
     finalize(summed, c_rows, row0)
+
+
+def gather_rows(c_full: torch.Tensor, rows: int, group=None) -> None:
+    """All-gather in place: every rank has written rows [r*rows, (r+1)*rows) of the contiguous ``c_full`` [M, N]."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    r = dist.get_rank(group)
+    mine = c_full[r * rows:(r + 1) * rows]
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(c_full, mine.clone(), group=group)
+    else:
+        # gloo (CPU test path): gather the rows as bytes, whatever the 16-bit element type is
+        mine_b = mine.contiguous().view(torch.uint8)
+        parts = [torch.empty_like(mine_b) for _ in range(world)]
+        dist.all_gather(parts, mine_b.clone(), group=group)
+        for g, part in enumerate(parts):
+            c_full[g * rows:(g + 1) * rows].copy_(part.view(c_full.dtype).view(mine.shape))
+
+
+def splitk_gemm_step(compute_partial: Callable[[KSlice, torch.Tensor], None],
+                     finalize: Callable[[torch.Tensor, torch.Tensor, int], None],
+                     partial: torch.Tensor, c_full: torch.Tensor, K: int, group=None) -> None:
+    """The multi-GPU split-K GEMM as ``bench.py --gpus N`` times it, C complete on every rank afterwards:
+
+        slice GEMM -> fp32 partial [M, N]   (compute_partial; zero it for an empty slice)
+        reduce-scatter of the partials      (rank r keeps rows [r*M/G, (r+1)*M/G) of the sum)
+        finalize those rows                 (finalize(sum_rows, c_full[rows of r], row0): epilogue + convert)
+        all-gather of the finished rows     (in place in ``c_full`` [M, N], contiguous)
+
+    M must be divisible by the world size.  One rank: GEMM + finalize only.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    M = partial.shape[0]
+    assert M % world == 0, "M must be divisible by the world size"
+    rows = M // world
+    compute_partial(partition(K, world)[rank], partial)
+    summed = partial if world == 1 else reduce_partials(partial, "reduce_scatter", group)
+    finalize(summed, c_full[rank * rows:(rank + 1) * rows], rank * rows)
+    if world > 1:
+        gather_rows(c_full, rows, group)
