@@ -40,7 +40,8 @@ EXPORTS = (
     "wqgemm_version", "wqgemm_last_error", "wqgemm_is_supported", "wqgemm_workspace_bytes",
     "wqgemm_launch", "wqgemm_run_timed", "wqgemm_type_string", "wqgemm_kernel_name",
     "wqgemm_pack_int4", "wqgemm_pack_int4_host", "wqgemm_reduce_finalize", "wqgemm_splitk_kread",
-    "wqgemm_run_timed_rotating", "wqgemm_launch_noalloc",
+    "wqgemm_run_timed_rotating", "wqgemm_launch_noalloc", "wqgemm_splitk_multi_workspace_bytes",
+    "wqgemm_splitk_multi_step",
 )
 
 
@@ -86,6 +87,10 @@ def _load() -> C.CDLL:
     L.wqgemm_run_timed.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.wqgemm_run_timed_rotating.restype = C.c_int
     L.wqgemm_run_timed_rotating.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.wqgemm_splitk_multi_workspace_bytes.restype = C.c_size_t
+    L.wqgemm_splitk_multi_workspace_bytes.argtypes = [P, C.c_int32]
+    L.wqgemm_splitk_multi_step.restype = C.c_int
+    L.wqgemm_splitk_multi_step.argtypes = [P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.wqgemm_type_string.restype = C.c_int
     L.wqgemm_type_string.argtypes = [P, C.c_char_p, C.c_size_t]
     L.wqgemm_kernel_name.restype = C.c_int
@@ -145,6 +150,16 @@ def run_timed_rotating(p: Problem, workspace: int | None, stream: int | None, co
     ms = C.c_float(0.0)
     check(lib.wqgemm_run_timed_rotating(C.byref(p), workspace, stream, cold, repeat, rotating_count, C.byref(ms)))
     return float(ms.value)
+
+
+def splitk_multi_workspace_bytes(p: Problem, nranks: int) -> int:
+    return int(lib.wqgemm_splitk_multi_workspace_bytes(C.byref(p), nranks))
+
+
+def splitk_multi_step(p: Problem, comm: int | None, rank: int, nranks: int, workspace: int,
+                      stream: int | None = None) -> None:
+    """One rank's step of the multi-GPU split-K GEMM (comm: an ncclComm_t as an integer, or None for no exchange)."""
+    check(lib.wqgemm_splitk_multi_step(C.byref(p), comm, rank, nranks, workspace, stream))
 
 
 def type_string(p: Problem) -> str:

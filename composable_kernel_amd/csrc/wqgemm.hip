@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <type_traits>
 
 #define WQ_MAIN_TU
@@ -630,6 +631,44 @@ const char* dt_name(int dt)
 
 } // namespace
 
+// ---- multi-GPU split-K over RCCL -------------------------------------------------------------------------------
+// RCCL is bound at first use from the copy the process already holds (a PyTorch process ships its own), else from
+// the system one; libwqgemm.so itself carries no link-time dependency on it.
+namespace {
+struct RcclApi
+{
+    int (*reduce_scatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t)          = nullptr;
+    const char* (*error_string)(int)                                                = nullptr;
+    bool tried = false, ok = false;
+};
+RcclApi& rccl()
+{
+    static RcclApi api;
+    if(api.tried)
+        return api;
+    api.tried  = true;
+    void* h = nullptr;
+    for(const char* name : {"librccl.so.1", "librccl.so"})
+        if((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)))
+            break;
+    if(!h)
+        for(const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+                break;
+    if(!h)
+        return api;
+    api.reduce_scatter = (decltype(api.reduce_scatter))dlsym(h, "ncclReduceScatter");
+    api.all_gather     = (decltype(api.all_gather))dlsym(h, "ncclAllGather");
+    api.error_string   = (decltype(api.error_string))dlsym(h, "ncclGetErrorString");
+    api.ok             = api.reduce_scatter && api.all_gather;
+    return api;
+}
+constexpr int kNcclInt8 = 0, kNcclFloat32 = 7, kNcclSum = 0; // rccl.h: ncclDataType_t / ncclRedOp_t
+
+size_t out_elt_bytes(int dt) { return dt == WQ_F32 ? 4 : 2; }
+} // namespace
+
 extern "C" {
 
 const char* wqgemm_version(void) { return "wqgemm 0.1 (gfx950)"; }
@@ -964,6 +1003,80 @@ int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, ui
             }
             memcpy(out + (size_t)n * ld_bytes + 4 * g, &w, 4);
         }
+    return WQ_OK;
+}
+
+size_t wqgemm_splitk_multi_workspace_bytes(const wqgemm_problem* p, int32_t nranks)
+{
+    if(!p || nranks < 1 || p->M <= 0 || p->N <= 0 || p->M % nranks != 0)
+        return 0;
+    return ((size_t)p->M + (size_t)p->M / nranks) * p->N * sizeof(float);
+}
+
+int wqgemm_splitk_multi_step(const wqgemm_problem* p, void* nccl_comm, int32_t rank, int32_t nranks, void* workspace,
+                             void* stream)
+{
+    if(!p || !workspace)
+        return fail(WQ_ERR_INVALID, "splitk_multi_step: null problem or workspace");
+    if(nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(WQ_ERR_INVALID, "splitk_multi_step: rank %d outside [0, %d)", rank, nranks);
+    if(p->M <= 0 || p->N <= 0 || p->M % nranks != 0)
+        return fail(WQ_ERR_UNSUPPORTED, "splitk_multi_step: M (%d) must be a positive multiple of the rank count %d", p->M, nranks);
+    if(p->ldc != p->N || !p->c)
+        return fail(WQ_ERR_UNSUPPORTED, "splitk_multi_step: C must be contiguous (ldc == N): the row blocks are gathered in place");
+    if(p->k_batch > 1 || p->k_begin != 0 || p->k_end != 0)
+        return fail(WQ_ERR_INVALID, "splitk_multi_step: the problem describes this rank's whole K slice (k_batch, k_begin, k_end unset)");
+    if(p->c_dtype != WQ_F16 && p->c_dtype != WQ_BF16)
+        return fail(WQ_ERR_UNSUPPORTED, "splitk_multi_step: C must be fp16 or bf16");
+    hipStream_t s    = (hipStream_t)stream;
+    const int rows   = p->M / nranks, row0 = rank * rows;
+    float* partial   = (float*)workspace;
+    float* sum_rows  = partial + (size_t)p->M * p->N;
+    // 1. this rank's K slice -> fp32 partial (a rank without a slice passes K = 0 or a = NULL and contributes zeros)
+    if(p->K <= 0 || !p->a)
+        WQ_HIP(hipMemsetAsync(partial, 0, (size_t)p->M * p->N * sizeof(float), s));
+    else
+    {
+        wqgemm_problem g = *p;
+        g.c = partial, g.c_dtype = WQ_F32, g.ldc = p->N;
+        g.k_begin = 0, g.k_end = p->K, g.k_batch = 1;
+        if(const int rc = wqgemm_launch(&g, nullptr, stream); rc != WQ_OK)
+            return rc;
+    }
+    // 2. sum over the ranks; rank r keeps rows [r rows, (r + 1) rows)
+    const float* summed = partial + (size_t)row0 * p->N;
+    if(nccl_comm)
+    {
+        RcclApi& api = rccl();
+        if(!api.ok)
+            return fail(WQ_ERR_HIP, "splitk_multi_step: librccl.so.1 (ncclReduceScatter / ncclAllGather) could not be loaded");
+        const int rc = api.reduce_scatter(partial, sum_rows, (size_t)rows * p->N, kNcclFloat32, kNcclSum, nccl_comm, s);
+        if(rc != 0)
+            return fail(WQ_ERR_HIP, "ncclReduceScatter failed: %s", api.error_string ? api.error_string(rc) : "?");
+        summed = sum_rows;
+    }
+    // 3. epilogue + convert of this rank's rows, written in place into C; per-row / full-matrix D operands move with
+    //    the row offset
+    wqgemm_problem f = *p;
+    f.M              = rows;
+    f.K              = p->K > 0 ? p->K : 64;
+    f.c              = (uint8_t*)p->c + (size_t)row0 * p->ldc * out_elt_bytes(p->c_dtype);
+    const bool mm    = p->epilogue == WQ_EPI_MULTIPLY_MULTIPLY || p->epilogue == WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU;
+    if(f.d0)
+        f.d0 = (const uint8_t*)p->d0 + (size_t)row0 * p->ldd0 * (mm ? 4 : 2);
+    if(f.d1)
+        f.d1 = (const uint8_t*)p->d1 + (mm ? (size_t)row0 * 4 : (size_t)row0 * p->ldd1 * 2);
+    if(const int rc = wqgemm_reduce_finalize(&f, summed, 1, stream); rc != WQ_OK)
+        return rc;
+    // 4. every rank receives every row block
+    if(nccl_comm)
+    {
+        RcclApi& api       = rccl();
+        const size_t bytes = (size_t)rows * p->N * out_elt_bytes(p->c_dtype);
+        const int rc       = api.all_gather((const uint8_t*)p->c + (size_t)rank * bytes, p->c, bytes, kNcclInt8, nccl_comm, s);
+        if(rc != 0)
+            return fail(WQ_ERR_HIP, "ncclAllGather failed: %s", api.error_string ? api.error_string(rc) : "?");
+    }
     return WQ_OK;
 }
 

@@ -215,6 +215,24 @@ int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, ui
 int wqgemm_reduce_finalize(const wqgemm_problem* p, const float* partials, int32_t k_batch,
                            void* stream);
 
+/* Multi-GPU split-K, one step on ONE rank (one process per GPU; every rank of the communicator makes the same call
+ * on its own stream).  The reference has no communication code; the flow keeps the shape of its in-GPU split-K --
+ * partial GEMMs, fp32 slabs, sum, convert (impl/device_gemm_xdl_cshuffle_v3r1.hpp:209-270) -- with the sum done by
+ * RCCL over xGMI:
+ *   1. this rank's K slice -> fp32 partial [M][N]         (p describes the slice: a / b point at it, K = its length;
+ *                                                          K = 0 or a = NULL: an empty slice, zeros)
+ *   2. ncclReduceScatter(fp32, sum): rank r keeps rows [r M/G, (r+1) M/G) of the sum
+ *   3. wqgemm_reduce_finalize of those rows into p->c     (p's epilogue; D operands addressed by global row)
+ *   4. ncclAllGather in place: p->c [M][N] complete on every rank
+ * p->c must be contiguous (ldc == N), fp16 or bf16; M a multiple of nranks; k_batch / k_begin / k_end unset.
+ * nccl_comm: an ncclComm_t of nranks ranks (RCCL is bound at run time from the copy already loaded in the process,
+ * else librccl.so.1); NULL = no exchange, the rank's own partial stands for the sum (single-process rehearsals).
+ * workspace: wqgemm_splitk_multi_workspace_bytes(p, nranks) = (M + M/nranks) * N * 4 bytes of device memory.
+ * Slices follow wqgemm_splitk_kread(K_total, nranks, 64): rank g owns [g KRead, min(K_total, (g+1) KRead)). */
+size_t wqgemm_splitk_multi_workspace_bytes(const wqgemm_problem* p, int32_t nranks);
+int wqgemm_splitk_multi_step(const wqgemm_problem* p, void* nccl_comm, int32_t rank, int32_t nranks, void* workspace,
+                             void* stream);
+
 /* KRead of the split-K partition: ceil(K/(k_batch*granule))*granule
  * (gridwise_gemm_xdl_cshuffle_v3.hpp:192-197). */
 int32_t wqgemm_splitk_kread(int32_t K, int32_t k_batch, int32_t granule);

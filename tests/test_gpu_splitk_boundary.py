@@ -140,3 +140,72 @@ def test_rotating_timed_run_matches_plain():
     assert p.a == a_t.data_ptr() and p.b == b_t.data_ptr()     # the caller's problem is not modified
     with pytest.raises(capi.WqError):
         capi.run_timed_rotating(p, ws.data_ptr(), st, 1, 3, 65)
+
+
+def _rccl_single_rank_comm():
+    """A one-rank RCCL communicator made through the C API of the copy torch ships (what a C++ caller would hold)."""
+    import ctypes as C
+    import os
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    return rccl, comm
+
+
+def test_splitk_multi_step_c_abi(port):
+    """wqgemm_splitk_multi_step, the C-ABI form of the multi-GPU flow: (a) through a real one-rank RCCL communicator
+    (reduce-scatter and all-gather are issued) the result is the single-pass kernel's, bit for bit; (b) without
+    exchange, as ranks 0 and 1 of two, each row block lands at its row offset with its per-row epilogue operands."""
+    rng = np.random.default_rng(91)
+    M, N, K = 512, 512, 1024
+    from gpu_util import pack_on_device
+    a_t = dev(f16_bits(rng.uniform(-1, 1, (M, K))))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    b_t = pack_on_device(q, K, N)
+    s_t = dev(f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N)))
+    st = torch.cuda.current_stream().cuda_stream
+    c_ref = torch.zeros((M, N), dtype=torch.int16, device="cuda")
+    p_ref = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), s_t.data_ptr(), c_ref.data_ptr(), M, N, K,
+                                 flags=capi.FLAG_TILE_256)
+    capi.launch(p_ref, None, st)
+    torch.cuda.synchronize()
+
+    rccl, comm = _rccl_single_rank_comm()
+    c = torch.zeros((M, N), dtype=torch.int16, device="cuda")
+    p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), s_t.data_ptr(), c.data_ptr(), M, N, K, flags=capi.FLAG_TILE_256)
+    ws = torch.empty(capi.splitk_multi_workspace_bytes(p, 1), dtype=torch.uint8, device="cuda")
+    assert ws.numel() == 2 * M * N * 4
+    capi.splitk_multi_step(p, comm.value, 0, 1, ws.data_ptr(), st)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host_u16(c), host_u16(c_ref))
+    assert rccl.ncclCommDestroy(comm) == 0
+
+    # (b) two ranks rehearsed in one process, MultiplyMultiply with per-row d1: fp8 activations
+    a8 = dev(rng.choice(np.array([0x00, 0x38, 0x40, 0xB8, 0xC0], np.uint8), (M, K)))
+    d0 = dev(rng.uniform(0.5, 1.0, N).astype(np.float32))
+    d1 = dev(rng.uniform(0.5, 1.0, M).astype(np.float32))
+    kw = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0.data_ptr(), d1=d1.data_ptr())
+    c_ref.zero_()
+    capi.launch(capi.fpAintB_problem(a8.data_ptr(), b_t.data_ptr(), None, c_ref.data_ptr(), M, N, K, **kw), None, st)
+    c.fill_(0x7BFF)
+    p2 = capi.fpAintB_problem(a8.data_ptr(), b_t.data_ptr(), None, c.data_ptr(), M, N, K, **kw)
+    ws2 = torch.empty(capi.splitk_multi_workspace_bytes(p2, 2), dtype=torch.uint8, device="cuda")
+    capi.splitk_multi_step(p2, None, 1, 2, ws2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert (host_u16(c)[: M // 2] == 0x7BFF).all()          # rank 1 wrote only its rows
+    capi.splitk_multi_step(p2, None, 0, 2, ws2.data_ptr(), st)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host_u16(c), host_u16(c_ref))
+    # refusals: padded C, M not divisible
+    bad = capi.fpAintB_problem(a8.data_ptr(), b_t.data_ptr(), None, c.data_ptr(), M, N, K, ldc=N + 8, **kw)
+    with pytest.raises(capi.WqError):
+        capi.splitk_multi_step(bad, None, 0, 2, ws2.data_ptr(), st)
+    with pytest.raises(capi.WqError):
+        capi.splitk_multi_step(p2, None, 0, 3, ws2.data_ptr(), st)
