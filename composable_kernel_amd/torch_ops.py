@@ -31,8 +31,27 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
         raise ValueError(f"unknown epilogue {epilogue!r}")
     if (bias is None) != (epilogue in ("none", "fastgelu")):
         raise ValueError("bias goes with the add / add_fastgelu epilogues only")
+    if bits not in (4, 8):
+        raise ValueError(f"bits must be 4 (packed int4) or 8 (int8), got {bits}")
+    if x.dim() != 2 or scale.dim() != 1:
+        raise ValueError("x must be (M, K) and scale (N,)")
     M, K = x.shape
     N = scale.shape[0]
+    # the kernels read weight / scale / bias through raw pointers: shapes, dtypes, devices and contiguity are checked here
+    want = (N, K // 2) if bits == 4 else (N, K)
+    if bits == 4 and K % 8 != 0:
+        raise ValueError("packed int4 weights need K to be a multiple of 8")
+    if tuple(weight.shape) != want or weight.dtype not in (torch.uint8, torch.int8):
+        raise ValueError(f"weight must be an 8-bit tensor of shape {want} for bits = {bits}, got {tuple(weight.shape)} {weight.dtype}")
+    for name, t in (("weight", weight), ("scale", scale), ("bias", bias)):
+        if t is None:
+            continue
+        if t.device != x.device:
+            raise ValueError(f"{name} is on {t.device}, x on {x.device}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+    if bias is not None and (tuple(bias.shape) != (N,) or bias.dtype != x.dtype):
+        raise ValueError(f"bias must have shape ({N},) and x's dtype {x.dtype}, got {tuple(bias.shape)} {bias.dtype}")
     x = x.contiguous()
     # any M runs as it is: small-M kernel up to 64 rows, the tile kernels with a partial last row tile beyond
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)

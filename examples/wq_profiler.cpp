@@ -7,6 +7,7 @@
 //   gemm_quantization        the int8 row of profile_gemm.cpp:20-27 with example/14's requantisation epilogue
 // The data-type enums are extended for the weight-quantized forms this engine adds (listed in each usage text).
 // A stride of -1 (script/profile_mixed_gemm.sh:17-51) selects the packed default.
+#include <cmath>
 #include <functional>
 #include <iomanip>
 #include <iostream>
@@ -64,12 +65,23 @@ void report(const char* dtype, ck::index_t M, ck::index_t N, ck::index_t K, ck::
               << ms << " ms, " << tflops << " TFlops, " << gbs << " GB/s, " << name << extra << std::endl;
 }
 
-StreamConfig stream_config(bool time_kernel, int n_warmup, int n_iter)
+StreamConfig stream_config(bool time_kernel, int n_warmup, int n_iter, int rotating_count = 1)
 {
     StreamConfig cfg{nullptr, time_kernel};
-    cfg.cold_niters_ = n_warmup;
-    cfg.nrepeat_     = n_iter;
+    cfg.cold_niters_   = n_warmup;
+    cfg.nrepeat_       = n_iter;
+    cfg.flush_cache    = rotating_count > 1; // as profile_gemm_multiply_multiply_impl.hpp:238 sets it
+    cfg.rotating_count = rotating_count;
     return cfg;
+}
+
+// rotating_count from the "memory for rotating buffer" argument, as the reference derives it
+// (profiler/include/profiler/profile_gemm_multiply_multiply_impl.hpp:78-84): enough copies of the inputs to fill that many
+// bytes, at most one per timed iteration
+int rotating_count_for(uint64_t rotating_bytes, std::size_t input_bytes, int n_iter)
+{
+    const int copies = static_cast<int>(std::ceil(static_cast<double>(rotating_bytes) / static_cast<double>(input_bytes)));
+    return std::max(1, std::min(n_iter, copies));
 }
 
 bool parse_common(int argc, char* argv[], int first_fixed, Common& c)
@@ -241,8 +253,19 @@ int profile_gemm_splitk(int argc, char* argv[])
 int profile_gemm_quantization(int argc, char* argv[])
 {
     Common c;
-    if((argc != 14 && argc != 15) || !parse_common(argc, argv, 14, c) || c.data_type != 3)
+    // under the name "gemm" (profiler/src/profile_gemm.cpp:20-27,51-80) arguments 14, 15 are warm-up cycles and
+    // iterations; under "gemm_quantization" argument 14 is the requantisation scale
+    const bool as_gemm = std::string(argv[1]) == "gemm";
+    if((as_gemm ? (argc != 14 && argc != 16) : (argc != 14 && argc != 15)) || !parse_common(argc, argv, 14, c) || c.data_type != 3)
     {
+        if(as_gemm)
+        {
+            std::cout << "arg1: tensor operation (gemm: GEMM)\narg2: data type (3: int8 -- the requantised int8 GEMM, "
+                         "Activation_Mul_Clamp with scale 0.03; the reference's other data types have no quantized operand)\n"
+                      << kLayoutText << "arg8 to 13: M, N, K, StrideA, StrideB, StrideC\noptional:\narg14: number of warm-up "
+                                        "cycles (default 1)\narg15: number of iterations (default 10)\n";
+            return 1;
+        }
         std::cout << "arg1: tensor operation (gemm_quantization: int8 GEMM + Activation_Mul_Clamp)\n"
                   << "arg2: data type (3: int8)\n"
                   << kLayoutText << "arg8 to 13: M, N, K, StrideA, StrideB, StrideC\noptional:\narg14: requantisation scale (default 0.03)\n";
@@ -252,7 +275,8 @@ int profile_gemm_quantization(int argc, char* argv[])
     using Op  = dev::DeviceGemmQuantization_gfx950<Row, Col, Row, CDE>;
     auto stride = [](int v, int dflt) { return v < 0 ? dflt : v; };
     const int sa = stride(std::stoi(argv[11]), c.K), sb = stride(std::stoi(argv[12]), c.K), sc = stride(std::stoi(argv[13]), c.N);
-    const float requant = argc == 15 ? std::stof(argv[14]) : 0.03f;
+    const float requant = (!as_gemm && argc == 15) ? std::stof(argv[14]) : 0.03f;
+    const int n_warmup = (as_gemm && argc == 16) ? std::stoi(argv[14]) : 1, n_iter = (as_gemm && argc == 16) ? std::stoi(argv[15]) : 10;
     const auto m = static_cast<std::size_t>(c.M), n = static_cast<std::size_t>(c.N), k = static_cast<std::size_t>(c.K);
     Tensor<int8_t> a(HostTensorDescriptor({m, k}, {static_cast<std::size_t>(sa), 1}));
     Tensor<int8_t> b(HostTensorDescriptor({k, n}, {1, static_cast<std::size_t>(sb)}));
@@ -273,7 +297,7 @@ int profile_gemm_quantization(int argc, char* argv[])
         std::cout << name << " does not support this problem" << std::endl;
         return 0;
     }
-    const float ms = op.MakeInvoker().Run(arg, stream_config(c.time, 1, 10));
+    const float ms = op.MakeInvoker().Run(arg, stream_config(c.time, n_warmup, n_iter));
     hip_check_error(hipDeviceSynchronize());
     bool pass = true;
     if(c.verify)
@@ -292,7 +316,7 @@ int profile_gemm_quantization(int argc, char* argv[])
 
 // ---- fp8 activations x int4 weights, MultiplyMultiply ----------------------------------------------------------------
 template <typename ADataType, bool NoSpecials>
-int run_mm(const Common& c, ck::index_t sa, ck::index_t sb, ck::index_t se, int n_warmup, int n_iter)
+int run_mm(const Common& c, ck::index_t sa, ck::index_t sb, ck::index_t se, int n_warmup, int n_iter, uint64_t rotating)
 {
     using CDE = ck::tensor_operation::element_wise::MultiplyMultiply;
     using Op  = dev::DeviceGemmMultiplyMultiply_WeightQuant_gfx950<Row, Col, Row, ADataType, ck::wq_int4x2_t, ck::half_t, CDE,
@@ -349,7 +373,10 @@ int run_mm(const Common& c, ck::index_t sa, ck::index_t sb, ck::index_t se, int 
         std::cout << name << " does not support this problem" << std::endl;
         return 0;
     }
-    const float ms = op.MakeInvoker().Run(arg, stream_config(c.time, n_warmup, n_iter));
+    const int rotating_count =
+        rotating_count_for(rotating, a.mData.size() + packed.size() + 4 * (d0.mData.size() + d1.mData.size()), n_iter);
+    std::cout << "rotating count: " << rotating_count << std::endl;
+    const float ms = op.MakeInvoker().Run(arg, stream_config(c.time, n_warmup, n_iter, rotating_count));
     hip_check_error(hipDeviceSynchronize());
     bool pass = true;
     if(c.verify)
@@ -379,22 +406,24 @@ int profile_gemm_multiply_multiply(int argc, char* argv[])
                      "matrix core; 10: f8 E4M3FN@int4 -> f16, fp8 matrix core)\n"
                   << kLayoutText << "arg8 to 15: M, N, K, StrideA, StrideB, StrideD0, StrideD1, StrideE\noptional:\n"
                   << "arg16: number of warm-up cycles (default 1)\narg17: number of iterations (default 10)\n"
-                  << "arg18: memory for rotating buffer (accepted, unused)\n";
+                  << "arg18: memory for rotating buffer (default 0, size in MB)\n";
         return 1;
     }
     auto stride = [](int v, int dflt) { return v < 0 ? dflt : v; };
     const int sa = stride(std::stoi(argv[11]), c.K), sb = stride(std::stoi(argv[12]), c.K), se = stride(std::stoi(argv[15]), c.N);
     const int n_warmup = argc == 19 ? std::stoi(argv[16]) : 1, n_iter = argc == 19 ? std::stoi(argv[17]) : 10;
+    const uint64_t rotating = argc == 19 ? std::stoull(argv[18]) * 1024 * 1024 : 0;
     if(c.data_type == 8)
-        return run_mm<ck::f8_t, false>(c, sa, sb, se, n_warmup, n_iter);
+        return run_mm<ck::f8_t, false>(c, sa, sb, se, n_warmup, n_iter, rotating);
     if(c.data_type == 9)
-        return run_mm<ck::f8_t, true>(c, sa, sb, se, n_warmup, n_iter);
-    return run_mm<ck::wq_f8_e4m3fn_t, false>(c, sa, sb, se, n_warmup, n_iter);
+        return run_mm<ck::f8_t, true>(c, sa, sb, se, n_warmup, n_iter, rotating);
+    return run_mm<ck::wq_f8_e4m3fn_t, false>(c, sa, sb, se, n_warmup, n_iter, rotating);
 }
 
 const Register r0("gemm_fpAintB", "GEMM with weight-only quantized B (fp16 / bf16 x int4 / int8)", profile_gemm_fpaintb);
 const Register r1("gemm_splitk", "Split-K GEMM with weight-only quantized B", profile_gemm_splitk);
 const Register r2("gemm_quantization", "int8 GEMM + Activation_Mul_Clamp", profile_gemm_quantization);
+const Register r2g("gemm", "GEMM (data type 3: int8, requantised)", profile_gemm_quantization);
 const Register r3("gemm_multiply_multiply", "GEMM_Multiply_Multiply (fp8 x int4)", profile_gemm_multiply_multiply);
 
 } // namespace

@@ -149,6 +149,11 @@ def test_reference_client_example30_sources_dropin(name):
     ("gemm_multiply_multiply", 8, 1, 1, 2, 0, 1, 256, 256, 512, -1, -1, 0, 0, -1),
     ("gemm_multiply_multiply", 9, 1, 1, 2, 0, 1, 256, 512, 512, -1, -1, 0, 0, -1),
     ("gemm_multiply_multiply", 10, 1, 1, 1, 0, 1, 512, 256, 512, -1, -1, 0, 0, -1),
+    # arg16-18: warm-up cycles, iterations, memory for the rotating buffer in MB (the reference's flush-cache timing mode)
+    ("gemm_multiply_multiply", 10, 1, 1, 2, 0, 1, 1024, 1024, 1024, -1, -1, 0, 0, -1, 2, 9, 16),
+    # the reference's plain "gemm" operation name with data type 3 (int8), optional warm-up / iteration counts
+    ("gemm", 3, 1, 1, 2, 0, 1, 512, 512, 512, -1, -1, -1),
+    ("gemm", 3, 1, 1, 1, 0, 1, 300, 100, 512, -1, -1, -1, 2, 5),
 ])
 def test_profiler_cli(args):
     """ckProfiler-style command line (operation name, data type, layout, verify, init, log, time, sizes, strides)."""
@@ -157,3 +162,6 @@ def test_profiler_cli(args):
     assert "verification: PASS" in r.stdout
     if args[6]:
         assert "Best Perf for datatype" in r.stdout and "TFlops" in r.stdout
+    if len(args) == 18:
+        # 16 MB over (1 MiB A + 0.5 MiB B + 8 KiB D) -> 11 copies, capped by the 9 iterations
+        assert "rotating count: 9" in r.stdout

@@ -1077,6 +1077,17 @@ def test_torch_linear_over_packed_weights(tmp_path, bits, dt):
     assert torch.allclose(ys.cpu().double(), xs.cpu().double() @ wd.T, rtol=tol, atol=tol)
     # registered as a dispatcher operator (usable from torch.compile graphs through its fake implementation)
     assert torch.ops.wqgemm.fpaintb_linear is not None
+    # operands that would make the kernels read past an allocation or reinterpret bytes are refused before any launch
+    from composable_kernel_amd.torch_ops import fpaintb_linear
+    lin = WqLinear(pw)
+    xc = x[0].contiguous().cuda()
+    for kw in (dict(bits=5), dict(weight=lin.weight[:, :-1].contiguous()), dict(weight=lin.weight[:-1]),
+               dict(weight=lin.weight.cpu()), dict(bias=bias.cuda().float(), epilogue="add"),
+               dict(bias=bias.to(dt).cuda()[:-1].contiguous(), epilogue="add"), dict(weight=lin.weight.t().contiguous().t())):
+        args = dict(x=xc, weight=lin.weight, scale=lin.scale, bits=bits, epilogue="none", bias=None)
+        args.update(kw)
+        with pytest.raises((ValueError, TypeError, RuntimeError)):
+            fpaintb_linear(args["x"], args["weight"], args["scale"], args["bits"], args["epilogue"], args["bias"])
 
 
 def test_launch_is_graph_capturable(port):
