@@ -366,6 +366,61 @@ __device__ __forceinline__ f4_t apply_epilogue4(const EpilogueArgs& e, f4_t v, i
     return f4_t{lo[0], lo[1], hi[0], hi[1]};
 }
 
+// The broadcast forms of the D operands (ldd0 == ldd1 == 0) depend on the column only -- or, for MultiplyMultiply's
+// d1, on the row only -- so a tile epilogue can fetch them once per column block / row block instead of once per
+// accumulator fragment.  load_d0_cols4 / load_d1_cols4: the four values of columns n .. n+3 as fp32; load_d1_row: the
+// row's value.  apply_epilogue4_bcast performs the operations of apply_epilogue4 in the same order on them.
+template <int KIND>
+__device__ __forceinline__ f4_t load_d0_cols4(const EpilogueArgs& e, int n)
+{
+    if constexpr(KIND == 3 || KIND == 4)
+    {
+        const float* d = (const float*)e.d0 + n;
+        return f4_t{d[0], d[1], d[2], d[3]};
+    }
+    else if constexpr(KIND == 2 || (KIND >= 6 && KIND <= 9))
+        return f4_t{load_d_as_f32(e.d0, n, e.c_dtype), load_d_as_f32(e.d0, n + 1, e.c_dtype),
+                    load_d_as_f32(e.d0, n + 2, e.c_dtype), load_d_as_f32(e.d0, n + 3, e.c_dtype)};
+    else
+        return f4_t{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int KIND>
+__device__ __forceinline__ f4_t load_d1_cols4(const EpilogueArgs& e, int n)
+{
+    if constexpr(KIND == 2)
+        return f4_t{load_d_as_f32(e.d1, n, e.c_dtype), load_d_as_f32(e.d1, n + 1, e.c_dtype),
+                    load_d_as_f32(e.d1, n + 2, e.c_dtype), load_d_as_f32(e.d1, n + 3, e.c_dtype)};
+    else
+        return f4_t{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int KIND>
+__device__ __forceinline__ float load_d1_row(const EpilogueArgs& e, int m)
+{
+    if constexpr(KIND == 3 || KIND == 4)
+        return ((const float*)e.d1)[m];
+    else
+        return 0.f;
+}
+
+template <int KIND>
+__device__ __forceinline__ f4_t apply_epilogue4_bcast(f4_t v, f4_t d0, f4_t d1n, float d1m)
+{
+    f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    if constexpr(KIND == 6 || KIND == 7)
+        lo = lo + f2_t{d0[0], d0[1]}, hi = hi + f2_t{d0[2], d0[3]};
+    else if constexpr(KIND == 2 || KIND == 3 || KIND == 4 || KIND == 8 || KIND == 9)
+        lo = lo * f2_t{d0[0], d0[1]}, hi = hi * f2_t{d0[2], d0[3]};
+    if constexpr(KIND == 2)
+        lo = lo + f2_t{d1n[0], d1n[1]}, hi = hi + f2_t{d1n[2], d1n[3]};
+    if constexpr(KIND == 3 || KIND == 4)
+        lo = lo * f2_t{d1m, d1m}, hi = hi * f2_t{d1m, d1m};
+    if constexpr(KIND == 1 || KIND == 2 || KIND == 4 || KIND == 7 || KIND == 9)
+        lo = fast_gelu2(lo), hi = fast_gelu2(hi);
+    return f4_t{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // four fp32 values -> four 16-bit outputs in two registers (fp16: round to nearest even; bf16: truncation)
 template <bool BF16>
 __device__ __forceinline__ u2_t pack_out4(f4_t y)
@@ -404,6 +459,24 @@ __device__ __forceinline__ int8_t requant_epilogue(int kind, float requant, int 
     y = fminf(fmaxf(requant * y, -128.f), 127.f);
     return (int8_t)y;
 }
+
+// The same family on one accumulator fragment (four consecutive columns of a row), packed into four bytes, with the
+// per-column work hoisted by the caller: bias4 = the columns' bias (zeros for kinds without one), relu_floor = 0 for the
+// Relu kinds and -infinity otherwise (max(y, 0) is the reference's y > 0 ? y : 0 on converted integers).
+__device__ __forceinline__ uint32_t requant_pack4(i4_t acc, i4_t bias4, float relu_floor, float requant)
+{
+    uint32_t pk = 0;
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+    {
+        float y = fmaxf((float)(acc[j] + bias4[j]), relu_floor);
+        y       = fminf(fmaxf(requant * y, -128.f), 127.f);
+        pk |= (uint32_t)(uint8_t)(int8_t)y << (8 * j);
+    }
+    return pk;
+}
+
+__device__ __forceinline__ float requant_relu_floor(int kind) { return kind == 10 || kind == 12 ? 0.f : -__builtin_inff(); }
 
 __device__ __forceinline__ uint16_t cvt_out16(float v, int c_dtype)
 {

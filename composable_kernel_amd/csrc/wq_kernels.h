@@ -144,20 +144,53 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
     constexpr int PHASES = MT * RSTEP == 256 ? 2 : 1;
     constexpr int MTP    = MT / PHASES;
     uint16_t* cg = (uint16_t*)p.c + (size_t)m0 * p.ldc + n0;
-#pragma unroll
-    for(int ph = 0; ph < PHASES; ++ph)
+    // D operands in their broadcast forms: one fetch per column block (and per row block for MultiplyMultiply's
+    // per-row d1) instead of one per fragment
+    const bool bcast = KIND != 0 && KIND != 1 && p.epi.ldd0 == 0 && p.epi.ldd1 == 0;
+    f4_t d0c[NT], d1c[NT];
+    if(bcast)
     {
 #pragma unroll
         for(int nt = 0; nt < NT; ++nt)
+        {
+            const int n = n0 + col_w + nt * CSTEP + fq * 4;
+            d0c[nt] = load_d0_cols4<KIND>(p.epi, n), d1c[nt] = load_d1_cols4<KIND>(p.epi, n);
+        }
+    }
+#pragma unroll
+    for(int ph = 0; ph < PHASES; ++ph)
+    {
+        if(bcast)
+        {
+            float d1r[MTP];
 #pragma unroll
             for(int mi = 0; mi < MTP; ++mi)
-            {
-                const int mt = ph * MTP + mi;
-                const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
-                const int m = min(m0 + r, p.M - 1); // rows of a partial last tile past M: keep per-row operand reads in range
-                const u2_t pk = pack_out4<BF16>(apply_epilogue4<KIND>(p.epi, acc[nt][mt], m, n0 + c));
-                *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
-            }
+                d1r[mi] = load_d1_row<KIND>(p.epi, min(m0 + row_w + (ph * MTP + mi) * RSTEP + fr, p.M - 1));
+#pragma unroll
+            for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for(int mi = 0; mi < MTP; ++mi)
+                {
+                    const int mt = ph * MTP + mi;
+                    const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
+                    const u2_t pk = pack_out4<BF16>(apply_epilogue4_bcast<KIND>(acc[nt][mt], d0c[nt], d1c[nt], d1r[mi]));
+                    *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
+                }
+        }
+        else
+        {
+#pragma unroll
+            for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for(int mi = 0; mi < MTP; ++mi)
+                {
+                    const int mt = ph * MTP + mi;
+                    const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
+                    const int m = min(m0 + r, p.M - 1); // rows of a partial last tile past M: keep per-row operand reads in range
+                    const u2_t pk = pack_out4<BF16>(apply_epilogue4<KIND>(p.epi, acc[nt][mt], m, n0 + c));
+                    *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
+                }
+        }
         __syncthreads();
         constexpr int ROWS_PH = 256 / PHASES;     // rows streamed out in this phase
         constexpr int ITERS   = ROWS_PH / 16;     // 8 waves x 2 rows per wave-instruction
@@ -415,17 +448,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     tile_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
 }
 
-#ifdef WQ_MAIN_TU // the non-template kernels below are emitted by wqgemm.hip only
-
-// ---------------------------------------------------------------------------------------------
-// int8 x int8 -> int32 MFMA kernel with the Activation_Mul_Clamp requantisation epilogue
-// (example/14_gemm_quantization, client_example/09_quantization).  128 x 128 x 128 tile: with one
-// byte per element a 128-deep K tile has the same 128-byte rows as the fp16 kernel's 64-deep tile, so
-// staging, swizzle and fragment addressing are shared; both operands go HBM -> LDS by LDS-DMA and
-// straight into v_mfma_i32_16x16x64_i8 (16 consecutive k per lane and operand).  Weights are the
-// first operand: lane l owns C[m = l & 15][n = 4 (l >> 4) + j] and stores 4 int8 at once.  Any M >= 1 and any
-// N % 4 == 0 (the last row and column tiles may be partial); K in whole tiles.
-// ---------------------------------------------------------------------------------------------
+// Parameters of the int8 x int8 requantised GEMM kernels.
 struct I8GemmParams
 {
     const void* a; // int8 row-major (M, lda)
@@ -437,6 +460,18 @@ struct I8GemmParams
     int kind;            // wq_epilogue of the requantisation family (5, 10, 11, 12)
     const int32_t* bias; // N values for kinds 11 and 12
 };
+
+#ifdef WQ_MAIN_TU // the non-template kernels below are emitted by wqgemm.hip only
+
+// ---------------------------------------------------------------------------------------------
+// int8 x int8 -> int32 MFMA kernel with the Activation_Mul_Clamp requantisation epilogue
+// (example/14_gemm_quantization, client_example/09_quantization).  128 x 128 x 128 tile: with one
+// byte per element a 128-deep K tile has the same 128-byte rows as the fp16 kernel's 64-deep tile, so
+// staging, swizzle and fragment addressing are shared; both operands go HBM -> LDS by LDS-DMA and
+// straight into v_mfma_i32_16x16x64_i8 (16 consecutive k per lane and operand).  Weights are the
+// first operand: lane l owns C[m = l & 15][n = 4 (l >> 4) + j] and stores 4 int8 at once.  Any M >= 1 and any
+// N % 4 == 0 (the last row and column tiles may be partial); K in whole tiles.
+// ---------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
 {
@@ -515,19 +550,25 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
             __syncthreads();
         }
     }
+    const float relu_floor = requant_relu_floor(p.kind);
 #pragma unroll
     for(int nt = 0; nt < 4; ++nt)
+    {
+        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+        i4_t bias4  = {0, 0, 0, 0};
+        if(p.kind >= 11)
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                bias4[j] = p.bias[min(n + j, p.N - 1)];
 #pragma unroll
         for(int mt = 0; mt < 4; ++mt)
         {
-            const int m = m0 + wm * 64 + mt * 16 + fr, n = n0 + wn * 64 + nt * 16 + fq * 4;
-            uint32_t pk = 0;
-#pragma unroll
-            for(int j = 0; j < 4; ++j)
-                pk |= (uint32_t)(uint8_t)requant_epilogue(p.kind, p.requant, acc[nt][mt][j], p.bias, min(n + j, p.N - 1)) << (8 * j);
+            const int m       = m0 + wm * 64 + mt * 16 + fr;
+            const uint32_t pk = requant_pack4(acc[nt][mt], bias4, relu_floor, p.requant);
             if(m < p.M && n < p.N) // partial last row / column tile (N % 4 == 0)
                 *(uint32_t*)((int8_t*)p.c + (size_t)m * p.ldc + n) = pk;
         }
+    }
 }
 
 
@@ -657,18 +698,23 @@ __global__ __launch_bounds__(512) void wq_gemm_i8_mfma_256(const I8GemmParams p)
     __syncthreads();
     // requantise into an LDS image of the tile (256 rows x 256 bytes, pitch 272), then stream whole rows out
     constexpr int PITCH = 256 + 16;
+    const float relu_floor = requant_relu_floor(p.kind);
 #pragma unroll
     for(int nt = 0; nt < 4; ++nt)
+    {
+        const int c = wn * 64 + nt * 16 + fq * 4;
+        i4_t bias4  = {0, 0, 0, 0};
+        if(p.kind >= 11)
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                bias4[j] = p.bias[n0 + c + j];
 #pragma unroll
         for(int mt = 0; mt < 8; ++mt)
         {
-            const int r = wm * 128 + mt * 16 + fr, c = wn * 64 + nt * 16 + fq * 4;
-            uint32_t pk = 0;
-#pragma unroll
-            for(int j = 0; j < 4; ++j)
-                pk |= (uint32_t)(uint8_t)requant_epilogue(p.kind, p.requant, acc[nt][mt][j], p.bias, n0 + c + j) << (8 * j);
-            *(uint32_t*)(lds + r * PITCH + c) = pk;
+            const int r                        = wm * 128 + mt * 16 + fr;
+            *(uint32_t*)(lds + r * PITCH + c) = requant_pack4(acc[nt][mt], bias4, relu_floor, p.requant);
         }
+    }
     __syncthreads();
     int8_t* cg = (int8_t*)p.c + (size_t)m0 * p.ldc + n0;
 #pragma unroll
