@@ -57,6 +57,7 @@ class Problem(C.Structure):
         ("d0", C.c_void_p), ("d1", C.c_void_p),
         ("k_batch", C.c_int32), ("k_begin", C.c_int32), ("k_end", C.c_int32), ("flags", C.c_int32),
         ("ldd0", C.c_int32), ("ldd1", C.c_int32),
+        ("scale_group_k", C.c_int32), ("ld_scale", C.c_int32),
     ]
 
 
@@ -198,7 +199,7 @@ def splitk_kread(K: int, k_batch: int, granule: int = 64) -> int:
 def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, lda=None, ldb=None,
                     ldc=None, epilogue=EPI_PASSTHROUGH, d0=None, d1=None, k_batch=1, k_begin=0,
                     k_end=0, c_dtype=None, b_layout=COL_MAJOR, a_layout=ROW_MAJOR, requant=0.0, flags=0,
-                    ldd0=0, ldd1=0) -> Problem:
+                    ldd0=0, ldd1=0, scale_group_k=0, ld_scale=0) -> Problem:
     """Fill a Problem from raw device pointers (ints).  Strides default to packed tensors."""
     p = Problem()
     p.a_dtype, p.b_dtype, p.scale_dtype = a_dtype, b_dtype, a_dtype
@@ -213,4 +214,5 @@ def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, 
     p.d0, p.d1 = d0, d1
     p.k_batch, p.k_begin, p.k_end, p.flags = k_batch, k_begin, k_end, flags
     p.ldd0, p.ldd1 = ldd0, ldd1
+    p.scale_group_k, p.ld_scale = scale_group_k, ld_scale
     return p

@@ -123,9 +123,18 @@ __device__ __forceinline__ void dequant8_i4_f16_stage(u4_t& v, const ScaleReg<A_
 // STAMP: diagnostic build only -- every wave of workgroup 0 accumulates, per section kind, the shader
 // cycles spent working and the cycles spent waiting at the section's barrier, and writes the sums to
 // p.dbg (no output value depends on them; the product never launches this instantiation).
-template <int AK, int BKIND, int WM, int SCHED, bool STAMP = false>
+//
+// GROUPED (SCHED 5, fp16 activations): group-wise weight scales, groups of a multiple of 64 consecutive k, so a K
+// tile lies inside one group.  The scales of a wave's own columns travel with the tile: one more LDS-DMA piece
+// (4 bytes per lane) behind the first part of tile t+2's pieces in L0(t), into a private 256-byte LDS area per wave and
+// tile parity behind the ring; the counted vmcnt waits allow one more operation in flight.  The scale registers are
+// swapped at the head of M1(t), between the dequantisation of (t, k-step 1) and that of (t+1, k-step 0).
+constexpr int kGroupScaleLds = 8 * 2 * 256; // bytes of dynamic LDS behind Mfma256<>::LDS_BYTES in the GROUPED instances
+
+template <int AK, int BKIND, int WM, int SCHED, bool STAMP = false, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
 {
+    static_assert(!GROUPED || (SCHED == 5 && AK == A_F16), "group-wise scales: default schedule, fp16 activations");
     using T = Mfma256<BKIND>;
     constexpr int WN = 8 / WM;        // waves along N
     constexpr int MT = 256 / WM / 16; // accumulator tiles along M per wave: 8 or 16
@@ -157,12 +166,37 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
     // the scale of column 16 nt + (l & 15) of the wave's NT * 16 columns)
     ScaleReg<AK> sc[NT];
     {
-        const uint16_t mine =
-            p.scale ? ((const uint16_t*)p.scale)[n0 + col_w + (lane & (NT * 16 - 1))] : unit_scale_bits<AK>();
+        uint16_t mine;
+        if constexpr(GROUPED)
+            mine = ((const uint16_t*)p.scale)[(size_t)(kz_begin / p.scale_group_k) * p.ld_scale + n0 + col_w + (lane & (NT * 16 - 1))];
+        else
+            mine = p.scale ? ((const uint16_t*)p.scale)[n0 + col_w + (lane & (NT * 16 - 1))] : unit_scale_bits<AK>();
 #pragma unroll
         for(int nt = 0; nt < NT; ++nt)
             sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));
     }
+    // GROUPED: this wave's scale area and the per-lane source of its LDS-DMA (lane l moves the scales of columns
+    // col_w + 2 l, + 1; lanes past the wave's NT * 16 columns move neighbours' scales nobody reads, clamped into the row)
+    uint8_t* const sc_lds = lds + T::LDS_BYTES + wave * 512;
+    const uint8_t* sc_src = (const uint8_t*)p.scale + (size_t)min(n0 + col_w + 2 * lane, p.N - 2) * 2;
+    int sc_rem            = 0; // k offset of the last tile handed to dma_scale inside its group
+    if constexpr(GROUPED)
+    {
+        sc_src += (size_t)(kz_begin / p.scale_group_k) * p.ld_scale * 2;
+        sc_rem = kz_begin % p.scale_group_k;
+    }
+    // called once per K tile in ascending order, from tile 1 on
+    auto dma_scale = [&](int tile) __attribute__((always_inline)) {
+        sc_rem += T::BK;
+        if(sc_rem >= p.scale_group_k)
+        {
+            sc_rem -= p.scale_group_k;
+            sc_src += (size_t)p.ld_scale * 2;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sc_src,
+                                         (__attribute__((address_space(3))) void*)(sc_lds + (tile & 1) * 256), 4, 0, 0);
+    };
+    uint16_t sc_next[NT];
     I4Consts i4c;
     i4c.init();
 
@@ -282,7 +316,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
         if(ntiles > 1)
         {
             stage(1, 1);
-            wait_vmcnt<T::DMA_PER_TILE>(); // tile 0 landed (this wave's part); tile 1 in flight
+            if constexpr(GROUPED)
+                dma_scale(1);
+            wait_vmcnt<T::DMA_PER_TILE + (GROUPED ? 1 : 0)>(); // tile 0 landed (this wave's part); tile 1 in flight
         }
         else
             wait_vmcnt<0>();
@@ -486,7 +522,11 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                 const bool more2 = t + 2 < ntiles;
                 // L0
                 if(more2)
+                {
                     stage_part(nxt2, t + 2, kD_begin, kD_mid);
+                    if constexpr(GROUPED)
+                        dma_scale(t + 2);
+                }
                 load_a(cur, 0);
                 sync(kL0);
                 // M0
@@ -496,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                 if(late)
                 {
                     if(more2)
-                        wait_vmcnt<D0>();
+                        wait_vmcnt<D0 + (GROUPED ? 1 : 0)>();
                     else
                         wait_vmcnt<0>();
                 }
@@ -508,11 +548,26 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                 if(!late)
                 {
                     if(more2)
-                        wait_vmcnt<D>();
+                        wait_vmcnt<D + (GROUPED ? 1 : 0)>();
                     else
                         wait_vmcnt<0>();
                 }
+                if constexpr(GROUPED && HAS_NEXT)
+                {
+                    // the scales of tile t+1 have landed (late waves waited in M0); fetched here, the read is
+                    // covered by the lgkmcnt(0) of the section end
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for(int nt = 0; nt < NT; ++nt)
+                        sc_next[nt] = *(const volatile uint16_t*)(sc_lds + ((t + 1) & 1) * 256 + (nt * 16 + fr) * 2);
+                }
                 sync(kL1);
+                if constexpr(GROUPED && HAS_NEXT)
+                {
+#pragma unroll
+                    for(int nt = 0; nt < NT; ++nt)
+                        sc[nt].set(sc_next[nt]);
+                }
                 // M1
                 __builtin_amdgcn_s_setprio(1);
                 mfma_section(wf2, wf, std::integral_constant<bool, HAS_NEXT>{}, nxt, 0);

@@ -12,7 +12,7 @@ namespace wq {
 
 namespace {
 
-template <int AK, int BKIND, int WM, int SCHED, bool STAMP>
+template <int AK, int BKIND, int WM, int SCHED, bool STAMP, bool GROUPED = false>
 int launch_v(const GemmParams& gp, dim3 grid, hipStream_t s)
 {
     // more than 64 KiB of dynamic LDS must be opted into once per device
@@ -20,15 +20,15 @@ int launch_v(const GemmParams& gp, dim3 grid, hipStream_t s)
     int dev                  = 0;
     if(hipGetDevice(&dev) != hipSuccess)
         return WQ_ERR_HIP;
-    constexpr int lds_bytes = Mfma256<BKIND>::LDS_BYTES;
+    constexpr int lds_bytes = Mfma256<BKIND>::LDS_BYTES + (GROUPED ? kGroupScaleLds : 0);
     if(dev >= 0 && dev < 64 && !opted_in[dev])
     {
-        if(hipFuncSetAttribute((const void*)wq_gemm_mfma_256<AK, BKIND, WM, SCHED, STAMP>,
+        if(hipFuncSetAttribute((const void*)wq_gemm_mfma_256<AK, BKIND, WM, SCHED, STAMP, GROUPED>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return WQ_ERR_HIP;
         opted_in[dev] = true;
     }
-    hipLaunchKernelGGL((wq_gemm_mfma_256<AK, BKIND, WM, SCHED, STAMP>), grid, dim3(512), lds_bytes, s, gp);
+    hipLaunchKernelGGL((wq_gemm_mfma_256<AK, BKIND, WM, SCHED, STAMP, GROUPED>), grid, dim3(512), lds_bytes, s, gp);
     return WQ_OK;
 }
 
@@ -43,6 +43,10 @@ int WQ_CAT(WQ_INST_AK, WQ_INST_BK)(const GemmParams& gp, dim3 grid, hipStream_t 
     if(gp.dbg) // diagnostic stamped builds (default wave grid only)
         return (variant & WQ_FLAG_DEQUANT_IN_L) ? launch_v<AK, BK, 1, 2, true>(gp, grid, s)
                                                  : launch_v<AK, BK, 1, 5, true>(gp, grid, s);
+#endif
+#if WQ_INST_AK == 0
+    if(gp.scale_group_k > 0) // group-wise scales: the default schedule and wave grid only
+        return launch_v<AK, BK, 1, 5, false, true>(gp, grid, s);
 #endif
     if(variant & WQ_FLAG_LOCKSTEP)
         return launch_v<AK, BK, 2, 0, false>(gp, grid, s);

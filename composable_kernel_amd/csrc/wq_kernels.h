@@ -36,6 +36,8 @@ struct GemmParams
     int a_scale;      // fp8 kernel: E8M0 block scale of the activation operand, replicated in all 4 bytes
     void* dbg;        // diagnostic builds only: per-wave cycle sums
     EpilogueArgs epi;
+    int scale_group_k; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
+    int ld_scale;
 };
 
 // XCD-aware block remap: blocks b and b + 8 share an XCD (and its L2) under round-robin
@@ -298,7 +300,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint8_t* lds_wave_base)
                                      0);
 }
 
-template <int AK, int BKIND>
+// GROUPED: group-wise scales (groups of a multiple of 64 consecutive k, so one K tile lies inside one group): the
+// scales of tile t + 1 are fetched while tile t is multiplied and installed behind the barrier that ends tile t.
+template <int AK, int BKIND, bool GROUPED = false>
 __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
 {
     using T = Mfma128<AK, BKIND>;
@@ -325,13 +329,20 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
     // One coalesced load of the wave's 64 scales, then a cross-lane broadcast: lane l needs the
     // scale of column 16 nt + (l & 15).
     ScaleReg<AK> sc[4];
-    {
-        // (columns past N in a partial last column tile re-read column N - 1: valid memory, results never stored)
-        const uint16_t mine = p.scale ? ((const uint16_t*)p.scale)[min(n0 + wn * 64 + lane, p.N - 1)] : unit_scale_bits<AK>();
+    // (columns past N in a partial last column tile re-read column N - 1: valid memory, results never stored)
+    const int scale_col = min(n0 + wn * 64 + lane, p.N - 1);
+    auto fetch_scale = [&](int k) __attribute__((always_inline)) -> uint16_t {
+        if constexpr(GROUPED)
+            return ((const uint16_t*)p.scale)[(size_t)(k / p.scale_group_k) * p.ld_scale + scale_col];
+        else
+            return p.scale ? ((const uint16_t*)p.scale)[scale_col] : unit_scale_bits<AK>();
+    };
+    auto install_scale = [&](uint16_t mine) __attribute__((always_inline)) {
 #pragma unroll
         for(int nt = 0; nt < 4; ++nt)
             sc[nt].set((uint16_t)__shfl((int)mine, nt * 16 + fr, 64));
-    }
+    };
+    install_scale(fetch_scale(kz_begin));
 
     // ---- staging addresses -------------------------------------------------------------------
     // A tile: 128 rows x 128 B.  One wave-instruction moves 8 rows (lane -> row lane/8, 16-byte
@@ -437,10 +448,18 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
         for(int t = 0; t < ntiles; ++t)
         {
             const int cur = t & 1;
+            uint16_t next_scale = 0;
             if(t + 1 < ntiles)
+            {
                 stage(cur ^ 1, t + 1);
+                if constexpr(GROUPED)
+                    next_scale = fetch_scale(kz_begin + (t + 1) * T::BK);
+            }
             compute(cur);
             __syncthreads();
+            if constexpr(GROUPED)
+                if(t + 1 < ntiles)
+                    install_scale(next_scale);
         }
     }
 
@@ -745,6 +764,7 @@ struct GenericParams
     int k_begin, k_end, k_per_z, partial;
     int a_dtype, b_dtype; // wq_dtype
     EpilogueArgs epi;
+    int scale_group_k, ld_scale; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
 };
 
 __device__ __forceinline__ float f8_fnuz_to_f32(uint8_t x)
@@ -849,10 +869,12 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
         return;
     }
 
-    const uint16_t sbits = p.scale ? ((const uint16_t*)p.scale)[n] : (p.a_dtype == 1 /*WQ_BF16*/ ? 0x3F80 : 0x3C00);
-    float acc            = 0.f;
+    uint16_t sbits = p.scale ? ((const uint16_t*)p.scale)[n] : (p.a_dtype == 1 /*WQ_BF16*/ ? 0x3F80 : 0x3C00);
+    float acc      = 0.f;
     for(int k = kb; k < ke; ++k)
     {
+        if(p.scale_group_k > 0)
+            sbits = ((const uint16_t*)p.scale)[(size_t)(k / p.scale_group_k) * p.ld_scale + n];
         int q;
         if(p.b_dtype == 6 /*WQ_I4_PACKED*/)
         {

@@ -204,6 +204,18 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     }
     if(!is16(p->a_dtype) && p->scale)
         return fail(WQ_ERR_UNSUPPORTED, "fp8 activations take their scales through the d0/d1 epilogue: scale must be NULL");
+    if(p->scale_group_k < 0 || p->ld_scale < 0)
+        return fail(WQ_ERR_INVALID, "scale_group_k and ld_scale must not be negative");
+    const bool grouped = p->scale_group_k > 0;
+    if(grouped)
+    {
+        if(!p->scale)
+            return fail(WQ_ERR_INVALID, "group-wise scales need the scale tensor");
+        if(p->a_dtype != WQ_F16)
+            return fail(WQ_ERR_UNSUPPORTED, "group-wise scales are implemented for fp16 activations");
+        if(p->ld_scale != 0 && p->ld_scale < p->N)
+            return fail(WQ_ERR_INVALID, "ld_scale too small");
+    }
     if(!slice)
     {
         // (a K-slice launch stores fp32 partials; its epilogue runs in wqgemm_reduce_finalize)
@@ -226,13 +238,14 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                        plan.k_per_z % 64 == 0 && (plan.k_end - plan.k_begin) % 64 == 0 &&
                        p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
                        ((uintptr_t)p->a % 16 == 0) && ((uintptr_t)p->b % 16 == 0) &&
-                       ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0);
+                       ((uintptr_t)p->c % 16 == 0) && ((uintptr_t)p->scale % 2 == 0) &&
+                       (!grouped || p->scale_group_k % 64 == 0); // a K tile must lie inside one scale group
     plan.route = tiled && !(p->flags & WQ_FLAG_GENERIC) ? ROUTE_MFMA128 : ROUTE_GENERIC;
     // Small M (decode-like shapes): HBM-bound, one pass over the weights; its own kernel with split-K for occupancy.
     {
         const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64; // k per super-step of wq_gemm_skinny
         const int klen_all  = plan.k_end - plan.k_begin;
-        const bool eligible = is16(p->a_dtype) && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
+        const bool eligible = is16(p->a_dtype) && !grouped && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                               p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 &&
                               klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
                               p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 &&
@@ -286,7 +299,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // without a workspace the general kernel runs.
     // Split-K by the caller (k_batch > 1) combines with it: the slabs come first in the workspace, the copy after them.
     if(plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) && is16(p->a_dtype) && !slice &&
-       plan.k_per_z % 64 == 0 &&
+       plan.k_per_z % 64 == 0 && (!grouped || p->scale_group_k % 64 == 0) &&
        p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_ROW_MAJOR && p->b_dtype != WQ_I4_PACKED &&
        p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % 16 == 0 && p->ldc % 4 == 0 &&
        (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0)
@@ -315,7 +328,11 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         plan.route   = ROUTE_MFMA128;
     }
     // (the last row tile may be partial, as in the 128-tile kernel; the 32x32-MFMA variant keeps whole tiles)
-    if(plan.route == ROUTE_MFMA128 && (p->M % 256 == 0 || !(p->flags & WQ_FLAG_MFMA_32X32)) && p->N % 256 == 0 &&
+    // (group-wise scales reach the 256-tile kernel by 4-byte LDS-DMA: 4-byte aligned scale rows, default variant only)
+    const bool grouped_256_ok =
+        !grouped || ((uintptr_t)p->scale % 4 == 0 && p->ld_scale % 2 == 0 &&
+                     !(p->flags & (WQ_FLAG_LOCKSTEP | WQ_FLAG_WAVES_2X4 | WQ_FLAG_DEQUANT_IN_L | WQ_FLAG_MFMA_32X32)));
+    if(plan.route == ROUTE_MFMA128 && grouped_256_ok && (p->M % 256 == 0 || !(p->flags & WQ_FLAG_MFMA_32X32)) && p->N % 256 == 0 &&
        p->ldc % 8 == 0 && !(p->flags & WQ_FLAG_TILE_128))
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
@@ -370,6 +387,12 @@ wq::EpilogueArgs epilogue_of(const wqgemm_problem* p)
 template <int AK, int BKIND>
 void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
 {
+    if constexpr(AK == wq::A_F16)
+        if(gp.scale_group_k > 0)
+        {
+            hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND, true>), grid, dim3(256), 0, s, gp);
+            return;
+        }
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
 }
 
@@ -425,6 +448,8 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.direct_store = (p->flags & WQ_FLAG_DIRECT_STORE) ? 1 : 0;
         gp.dbg          = g_dbg;
         gp.a_scale      = p->a_dtype == WQ_F8_FNUZ ? 0x7E7E7E7E : 0x7F7F7F7F;
+        gp.scale_group_k = p->scale_group_k > 0 ? p->scale_group_k : 0;
+        gp.ld_scale      = p->ld_scale > 0 ? p->ld_scale : p->N;
         {
             // Tiles are dealt to the 8 XCDs in contiguous runs of nwg/8 (xcd_remap); inside a run the
             // walk covers group_m tile rows x (run / group_m) tile columns.  Pick the group that
@@ -593,6 +618,8 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.a_dtype = p->a_dtype;
         gp.b_dtype = p->b_dtype;
         gp.epi     = epilogue_of(p);
+        gp.scale_group_k = p->scale_group_k > 0 ? p->scale_group_k : 0;
+        gp.ld_scale      = p->ld_scale > 0 ? p->ld_scale : p->N;
         const dim3 grid((p->N + 15) / 16, (p->M + 15) / 16, plan.k_batch);
         hipLaunchKernelGGL(wq::wq_gemm_generic, grid, dim3(256), 0, s, gp);
     }
@@ -933,11 +960,16 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
         snprintf(buf, n, "DeviceFpAintBGemm_SmallM_gfx950<256, 64, 64, 16x16x32, %s, %s, %s, StreamB, KBatch%d>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
     else if(plan.route == ROUTE_MFMA128 || plan.route == ROUTE_MFMA256)
+    {
+        char grp[32] = "";
+        if(p->scale_group_k > 0)
+            snprintf(grp, sizeof(grp), ", ScaleGroupK%d", p->scale_group_k);
         snprintf(buf, n,
                  "DeviceFpAintBGemm_Mfma_gfx950<%s, 64, 16x16x32, %s, %s, %s, LdsDma, "
-                 "DequantInRegister, KBatch%d>",
+                 "DequantInRegister, KBatch%d%s>",
                  plan.route == ROUTE_MFMA256 ? "512, 256, 256" : "256, 128, 128", dt_name(p->a_dtype),
-                 dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
+                 dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch, grp);
+    }
     else
         snprintf(buf, n, "DeviceWqGemm_Generic_gfx950<256, 16, 16, %s, %s, %s, KBatch%d>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);

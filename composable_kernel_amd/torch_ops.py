@@ -22,7 +22,8 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     """y[m, n] = epilogue( sum_k x[m, k] * dequant(weight[n, k], scale[n]) [, bias[n]] ).
 
     x (M, K) fp16 / bf16, row-major; weight uint8 (N, K/2) packed int4 (bits = 4) or int8 (N, K) (bits = 8);
-    scale and bias (N,) of x's dtype; epilogue in {"none", "fastgelu", "add", "add_fastgelu"}."""
+    scale and bias (N,) of x's dtype; epilogue in {"none", "fastgelu", "add", "add_fastgelu"}.
+    Group-wise scales (fp16 only): scale of shape (G, N), one row per group of K / G consecutive k."""
     if not x.is_cuda:
         raise RuntimeError("wqgemm::fpaintb_linear runs on the GPU only")
     if x.dtype not in _DT or scale.dtype != x.dtype:
@@ -33,10 +34,17 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
         raise ValueError("bias goes with the add / add_fastgelu epilogues only")
     if bits not in (4, 8):
         raise ValueError(f"bits must be 4 (packed int4) or 8 (int8), got {bits}")
-    if x.dim() != 2 or scale.dim() != 1:
-        raise ValueError("x must be (M, K) and scale (N,)")
+    if x.dim() != 2 or scale.dim() not in (1, 2):
+        raise ValueError("x must be (M, K) and scale (N,) or (groups, N)")
     M, K = x.shape
-    N = scale.shape[0]
+    N = scale.shape[-1]
+    group_k = 0
+    if scale.dim() == 2:
+        if scale.shape[0] == 0 or K % scale.shape[0] != 0:
+            raise ValueError(f"K = {K} is not a whole number of the {scale.shape[0]} scale groups")
+        if x.dtype != torch.float16:
+            raise TypeError("group-wise scales need float16 activations")
+        group_k = K // scale.shape[0]
     # the kernels read weight / scale / bias through raw pointers: shapes, dtypes, devices and contiguity are checked here
     want = (N, K // 2) if bits == 4 else (N, K)
     if bits == 4 and K % 8 != 0:
@@ -57,7 +65,8 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     p = capi.fpAintB_problem(x.data_ptr(), weight.data_ptr(), scale.data_ptr(), y.data_ptr(), M, N, K,
                              a_dtype=_DT[x.dtype], b_dtype=capi.I4_PACKED if bits == 4 else capi.I8,
-                             epilogue=_EPILOGUES[epilogue], d0=bias.data_ptr() if bias is not None else None)
+                             epilogue=_EPILOGUES[epilogue], d0=bias.data_ptr() if bias is not None else None,
+                             scale_group_k=group_k)
     nbytes = capi.workspace_bytes(p)  # optional scratch (the planner's split-K partials)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
@@ -67,7 +76,7 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
 
 @fpaintb_linear.register_fake
 def _(x, weight, scale, bits, epilogue, bias):
-    return x.new_empty((x.shape[0], scale.shape[0]))
+    return x.new_empty((x.shape[0], scale.shape[-1]))
 
 
 class WqLinear(torch.nn.Module):

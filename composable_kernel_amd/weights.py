@@ -1,5 +1,5 @@
-"""Offline weight preparation for the weight-quantized GEMM engine: per-channel symmetric quantisation, packing
-and a small on-disk container.
+"""Offline weight preparation for the weight-quantized GEMM engine: per-channel or group-wise symmetric
+quantisation, packing and a small on-disk container.
 
 The reference keeps quantised weights as one int8 (or int4-valued int8) per element and re-encodes them on the
 host right before the GEMM (example/64_fpAintB_gemm/common.hpp:51-83, UnsignedWeightPreprocessor).  Here that step
@@ -7,10 +7,16 @@ is done once, offline: weights are stored K-contiguous per output channel in the
 (``WQ_I4_PACKED``: two offset-binary nibbles per byte in the order documented at ``wqgemm_pack_int4``;
 ``WQ_I8``: plain int8), next to their per-channel scales.
 
+Group-wise scales (one scale per output channel and per ``group_k`` consecutive k) are stored as a (K / group_k, N)
+array, one row of N scales per group: the (K, N) scale tensor of the reference's fpAintB GEMM
+(library/include/ck/library/reference_tensor_operation/cpu/reference_fpAintB_gemm.hpp:62-127) with repeated rows
+collapsed, in the (K / block, N) shape of example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:126-152.
+
 Container (``save_packed`` / ``load_packed``): a NumPy ``.npz`` archive with the arrays ``weight`` (uint8 or int8,
-shape (N, K/2) or (N, K)), ``scale`` (uint16 bit patterns of fp16 / bf16, shape (N,)) and the 0-d entries
-``format`` ("wqgemm-weights-1"), ``bits`` (4 or 8), ``scale_dtype`` ("f16" or "bf16"), ``N`` and ``K``.  Loaded with
-``allow_pickle=False``.
+shape (N, K/2) or (N, K)), ``scale`` (uint16 bit patterns of fp16 / bf16, shape (N,), or (K / group_k, N) for
+group-wise scales) and the 0-d entries ``format`` ("wqgemm-weights-2"; "wqgemm-weights-1" files, which have no
+``group_k``, still load), ``bits`` (4 or 8), ``scale_dtype`` ("f16" or "bf16"), ``N``, ``K`` and ``group_k`` (0 = one scale
+per channel).  Loaded with ``allow_pickle=False``.
 """
 from __future__ import annotations
 
@@ -20,17 +26,19 @@ import numpy as np
 
 from . import capi
 
-FORMAT = "wqgemm-weights-1"
+FORMAT = "wqgemm-weights-2"
+FORMATS_READ = ("wqgemm-weights-1", FORMAT)
 
 
 @dataclass
 class PackedWeights:
     weight: np.ndarray      # uint8 (N, K//2) for 4 bits, int8 (N, K) for 8 bits; K contiguous
-    scale: np.ndarray       # uint16 bit patterns, (N,)
+    scale: np.ndarray       # uint16 bit patterns, (N,) or (K // group_k, N)
     bits: int
     scale_dtype: str        # "f16" | "bf16"
     N: int
     K: int
+    group_k: int = 0        # 0: one scale per output channel; g: one per channel and per g consecutive k
 
     @property
     def b_dtype(self) -> int:
@@ -71,17 +79,40 @@ def quantize_per_channel(w: np.ndarray, bits: int = 4, scale_dtype: str = "f16")
     return q, s_bits
 
 
-def pack(q: np.ndarray, scale_bits: np.ndarray, bits: int = 4, scale_dtype: str = "f16") -> PackedWeights:
-    """q int8 (N, K) -> the engine's device format."""
+def quantize_per_group(w: np.ndarray, group_k: int, bits: int = 4,
+                       scale_dtype: str = "f16") -> tuple[np.ndarray, np.ndarray]:
+    """quantize_per_channel applied to every group of ``group_k`` consecutive k of every output channel.
+
+    Returns (q int8 (N, K), scale bit patterns uint16 (K // group_k, N)).  K must be a multiple of group_k."""
+    if bits not in (4, 8):
+        raise ValueError("bits must be 4 or 8")
+    w = np.asarray(w, np.float32)
+    N, K = w.shape
+    if group_k <= 0 or K % group_k:
+        raise ValueError("K must be a multiple of group_k")
+    qmax = 2 ** (bits - 1) - 1
+    wg = w.reshape(N, K // group_k, group_k)
+    amax = np.abs(wg).max(axis=2)                                   # (N, groups)
+    s_bits = _to_bits(np.where(amax > 0, amax / qmax, 1.0), scale_dtype)
+    s = _from_bits(s_bits, scale_dtype)
+    q = np.clip(np.rint(wg / s[:, :, None]), -qmax - 1, qmax).astype(np.int8).reshape(N, K)
+    return q, np.ascontiguousarray(s_bits.T)
+
+
+def pack(q: np.ndarray, scale_bits: np.ndarray, bits: int = 4, scale_dtype: str = "f16", group_k: int = 0) -> PackedWeights:
+    """q int8 (N, K) -> the engine's device format; scale_bits (N,), or (K // group_k, N) with group_k > 0."""
     q = np.ascontiguousarray(q, np.int8)
     N, K = q.shape
+    scale_bits = np.ascontiguousarray(scale_bits, np.uint16)
+    if scale_bits.shape != ((K // group_k, N) if group_k else (N,)) or (group_k and K % group_k):
+        raise ValueError("scale shape does not match N, K and group_k")
     if bits == 4:
         if K % 8:
             raise ValueError("K must be a multiple of 8 for packed int4")
         weight = capi.pack_int4_host(q, K, N)
     else:
         weight = q
-    return PackedWeights(weight, np.ascontiguousarray(scale_bits, np.uint16), bits, scale_dtype, N, K)
+    return PackedWeights(weight, scale_bits, bits, scale_dtype, N, K, group_k)
 
 
 def unpack_int4(packed: np.ndarray, K: int) -> np.ndarray:
@@ -100,20 +131,23 @@ def dequantize(pw: PackedWeights) -> np.ndarray:
     """fp32 (N, K) weights as the kernels see them: q * scale rounded to the scale's 16-bit type."""
     q = unpack_int4(pw.weight, pw.K) if pw.bits == 4 else pw.weight
     s = _from_bits(pw.scale, pw.scale_dtype)
-    return _from_bits(_to_bits(q.astype(np.float32) * s[:, None], pw.scale_dtype), pw.scale_dtype)
+    s_nk = np.repeat(s.T, pw.group_k, axis=1) if pw.group_k else s[:, None]
+    return _from_bits(_to_bits(q.astype(np.float32) * s_nk, pw.scale_dtype), pw.scale_dtype)
 
 
 def save_packed(path: str, pw: PackedWeights) -> None:
     np.savez(path, format=np.array(FORMAT), bits=np.array(pw.bits), scale_dtype=np.array(pw.scale_dtype),
-             N=np.array(pw.N), K=np.array(pw.K), weight=pw.weight, scale=pw.scale)
+             N=np.array(pw.N), K=np.array(pw.K), group_k=np.array(pw.group_k), weight=pw.weight, scale=pw.scale)
 
 
 def load_packed(path: str) -> PackedWeights:
     with np.load(path, allow_pickle=False) as z:
-        if str(z["format"]) != FORMAT:
+        if str(z["format"]) not in FORMATS_READ:
             raise ValueError(f"{path}: not a {FORMAT} container")
-        pw = PackedWeights(z["weight"], z["scale"], int(z["bits"]), str(z["scale_dtype"]), int(z["N"]), int(z["K"]))
+        pw = PackedWeights(z["weight"], z["scale"], int(z["bits"]), str(z["scale_dtype"]), int(z["N"]), int(z["K"]),
+                           int(z["group_k"]) if "group_k" in z.files else 0)
     want = (pw.N, pw.K // 2) if pw.bits == 4 else (pw.N, pw.K)
-    if pw.weight.shape != want or pw.scale.shape != (pw.N,):
-        raise ValueError(f"{path}: array shapes do not match N = {pw.N}, K = {pw.K}, bits = {pw.bits}")
+    want_s = (pw.K // pw.group_k, pw.N) if pw.group_k > 0 else (pw.N,)
+    if pw.group_k < 0 or (pw.group_k and pw.K % pw.group_k) or pw.weight.shape != want or pw.scale.shape != want_s:
+        raise ValueError(f"{path}: array shapes do not match N = {pw.N}, K = {pw.K}, bits = {pw.bits}, group_k = {pw.group_k}")
     return pw

@@ -119,6 +119,17 @@ typedef struct wqgemm_problem
      * example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8.cpp:43-47).  Ignored by the int32 bias of the
      * requantisation epilogues (always one value per column). */
     int32_t ldd0, ldd1;
+    /* Group-wise weight scales.  scale_group_k = 0 (the default): one scale per column, `scale` holds N values.
+     * scale_group_k = g > 0: one scale per column and per group of g consecutive k -- `scale` is a row-major
+     * (ceil(K / g), N) tensor with row stride ld_scale >= N (0 = N) and the weight at (k, n) is dequantised with
+     * scale[(k / g) * ld_scale + n].  In the reference's terms this is the (K, N) scale tensor of
+     * ReferencefpAintBGemm (library/include/ck/library/reference_tensor_operation/cpu/reference_fpAintB_gemm.hpp:62-127)
+     * with rows repeating g times, per-channel scales being its strides-(0,1) case; the (K / block, N) shape follows
+     * the B1 scale tensor of example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:126-152.
+     * fp16 activations only.  Any g >= 1 runs on the general kernel; g a multiple of 64 (64, 128, ...) on the
+     * 128- and 256-tile matrix-core kernels.  k (and so the group index) counts from the start of the K range also
+     * for K slices and split-K. */
+    int32_t scale_group_k, ld_scale;
 } wqgemm_problem;
 
 /* Library version string, e.g. "wqgemm 0.1 (gfx950)". */

@@ -82,6 +82,7 @@ class Checker:
                          [_i8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int])
         tail = [C.c_int] if self._threaded else []
         self._fpaintb = sig("fpAintB_gemm_f16", None, [_u16p, _i8p, _u16p, _u16p] + [C.c_int] * 6 + tail)
+        self._fpaintb_g = sig("fpAintB_gemm_f16_grouped", None, [_u16p, _i8p, _u16p, _u16p] + [C.c_int] * 8 + tail)
         self._i8 = sig("gemm_i8_requant", None, [_i8p, _i8p, _i8p] + [C.c_int] * 6 + [C.c_float] + tail)
         self._i8b = sig("gemm_i8_bias_requant", None,
                         [_i8p, _i8p, C.c_void_p, _i8p] + [C.c_int] * 6 + [C.c_float, C.c_int] + tail)
@@ -125,6 +126,15 @@ class Checker:
         """a: uint16 (M,lda) fp16 bits; b: int8 column-major (N,ldb); scale: uint16 (N)."""
         c = np.zeros(1 + (M - 1) * ldc + (N - 1), dtype=np.uint16)
         self._fpaintb(a.ravel(), b.ravel(), scale, c, M, N, K, lda, ldb, ldc, *self._t(nthreads))
+        return c
+
+    def fpAintB_gemm_f16_grouped(self, a, b, scale, M, N, K, lda, ldb, ldc, group_k, ld_scale=None,
+                                 nthreads=None) -> np.ndarray:
+        """Group-wise scales: scale uint16 (ceil(K / group_k), ld_scale), one row of N scales per group_k consecutive k."""
+        ld_scale = ld_scale or N
+        c = np.zeros(1 + (M - 1) * ldc + (N - 1), dtype=np.uint16)
+        self._fpaintb_g(a.ravel(), b.ravel(), np.ascontiguousarray(scale, np.uint16).ravel(), c, M, N, K, lda, ldb, ldc,
+                        group_k, ld_scale, *self._t(nthreads))
         return c
 
     def gemm_i8_requant(self, a, b, M, N, K, lda, ldb, lde, requant, nthreads=None) -> np.ndarray:

@@ -182,6 +182,26 @@ void ckref_fpAintB_gemm_f16(const uint16_t* a, const int8_t* b, const uint16_t* 
     store2(tc, c);
 }
 
+// The same ReferencefpAintBGemm with a scale tensor that varies along k: lengths (K,N), strides (N,1), row k holding
+// the N scales of group k / group_k (group-wise scales: scale[(k / group_k) * ld_scale + n]).
+void ckref_fpAintB_gemm_f16_grouped(const uint16_t* a, const int8_t* b, const uint16_t* scale, uint16_t* c, int M,
+                                    int N, int K, int lda, int ldb, int ldc, int group_k, int ld_scale)
+{
+    using Ref = ck::tensor_operation::host::
+        ReferencefpAintBGemm<half_t, int8_t, half_t, half_t, float, PT, PT, PT>;
+    auto ta = load2<half_t>(a, M, K, lda, 1);
+    auto tb = load2<int8_t>(b, K, N, 1, ldb);
+    Tensor<half_t> ts(desc2(K, N, N, 1));
+    for(int k = 0; k < K; ++k)
+        for(int n = 0; n < N; ++n)
+            ts(k, n) = bits_to<half_t>(scale[(size_t)(k / group_k) * ld_scale + n]);
+    Tensor<half_t> tc(desc2(M, N, ldc, 1));
+    auto ref = Ref{};
+    auto inv = ref.MakeInvoker();
+    inv.Run(ref.MakeArgument(ta, tb, ts, tc, PT{}, PT{}, PT{}));
+    store2(tc, c);
+}
+
 // ReferenceGemm<int8,int8,int8,float,PT,PT,Activation_Mul_Clamp<PT>> (example/14 verify path).
 // A row-major lda, B column-major ldb, E row-major lde.
 void ckref_gemm_i8_requant(const int8_t* a, const int8_t* b, int8_t* e, int M, int N, int K,

@@ -398,6 +398,42 @@ void wqo_fpAintB_gemm_f16_partial(const uint16_t* a, const int8_t* b, const uint
     parallel_mn(fpaintb_f16_mn, &x, M, N, nthreads);
 }
 
+/* The same reference loop (reference_fpAintB_gemm.hpp:62-127) with a scale that also depends on k: the reference
+ * reads scale_k_n_(k, n) through a tensor descriptor, per-channel scales being the strides-(0,1) case.  Group-wise
+ * scales are the tensor whose rows repeat group_k times: scale(k, n) = scale[(k / group_k) * ld_scale + n], i.e. one
+ * row of N scales per group of group_k consecutive k (ceil(K / group_k) rows, the shape of the B1 scale tensor in
+ * example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:126-152 with a block of one column). */
+typedef struct
+{
+    const uint16_t* a;
+    const int8_t* b;
+    const uint16_t* scale;
+    uint16_t* c;
+    int K, lda, ldb, ldc, group_k, ld_scale;
+} fpaintb_grouped_ctx;
+
+static void fpaintb_f16_grouped_mn(void* p, int m, int n)
+{
+    const fpaintb_grouped_ctx* x = (const fpaintb_grouped_ctx*)p;
+    float acc                    = 0.f;
+    for(int k = 0; k < x->K; ++k)
+    {
+        const float s  = wqo_f16_to_f32(x->scale[(size_t)(k / x->group_k) * x->ld_scale + n]);
+        const float va = wqo_f16_to_f32(x->a[(size_t)m * x->lda + k]);
+        const float hq = (float)x->b[(size_t)n * x->ldb + k]; /* exact in half */
+        const float vb = wqo_f16_to_f32(wqo_f32_to_f16(hq * s));
+        acc += va * vb;
+    }
+    x->c[(size_t)m * x->ldc + n] = wqo_f32_to_f16(acc);
+}
+
+void wqo_fpAintB_gemm_f16_grouped(const uint16_t* a, const int8_t* b, const uint16_t* scale, uint16_t* c, int M,
+                                  int N, int K, int lda, int ldb, int ldc, int group_k, int ld_scale, int nthreads)
+{
+    fpaintb_grouped_ctx x = {a, b, scale, c, K, lda, ldb, ldc, group_k, ld_scale};
+    parallel_mn(fpaintb_f16_grouped_mn, &x, M, N, nthreads);
+}
+
 /* reference_gemm.hpp:60-108 with <int8,int8,int8,float,PT,PT,Activation_Mul_Clamp<PT>>
  * (example/14_gemm_quantization/gemm_xdl_quantization_int8.cpp:95-96): ComputeType = int8,
  * acc(float) += float(a) * float(b); e = Activation_Mul_Clamp(acc -> int32). */

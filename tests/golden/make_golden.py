@@ -210,6 +210,28 @@ def gemm_cases(ref) -> dict:
                                                                N, ep, dm0, N)
     out["bf16_dmat_e_col_ep2"] = ref.gemm_bf16_i8_dmat(out["bf16_a"], out["bf16_bcol"], None, M, N, K, K, 1, K, N, 2, dm0, N,
                                                        dm1, N + 8)
+
+    # ---- group-wise weight scales (one row of N fp16 scales per group_k consecutive k): the reference's
+    # ReferencefpAintBGemm given the (K, N) scale tensor whose rows repeat per group.  int4-range and int8 weights,
+    # groups of 64 and 128, a padded scale row (ld_scale = N + 8) and a ragged case with a partial last group.
+    def grouped(tag, M, N, K, lda, ldb, ldc, group_k, ld_scale, qlo, qhi, integer=False):
+        groups = (K + group_k - 1) // group_k
+        if integer:
+            a = f16_bits(np.round(rng.uniform(-2, 2, (M, lda))))
+            s = f16_bits(rng.integers(1, 4, (groups, ld_scale)).astype(np.float32))
+        else:
+            a = f16_bits(rng.uniform(-1, 1, (M, lda)))
+            s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, (groups, ld_scale)))
+        b = rng.integers(qlo, qhi + 1, (N, ldb)).astype(np.int8)
+        out[f"{tag}_shape"] = np.array([M, N, K, lda, ldb, ldc, group_k, ld_scale], np.int32)
+        out[f"{tag}_a"], out[f"{tag}_b"], out[f"{tag}_s"] = a, b, s
+        out[f"{tag}_c"] = ref.fpAintB_gemm_f16_grouped(a, b, s, M, N, K, lda, ldb, ldc, group_k, ld_scale)
+
+    grouped("grp64_i4", 48, 64, 256, 256, 256, 64, 64, 64, -8, 7)
+    grouped("grp128_i4", 48, 64, 256, 256, 256, 64, 128, 72, -8, 7)
+    grouped("grp64_i8", 32, 48, 128, 128, 128, 48, 64, 48, -128, 127)
+    grouped("grp_ragged_i4", 33, 20, 80, 88, 96, 24, 32, 20, -8, 7)
+    grouped("grp128_int_i4", 128, 128, 512, 512, 512, 128, 128, 128, -8, 7, integer=True)
     return out
 
 

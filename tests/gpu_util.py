@@ -35,7 +35,8 @@ def bits_to_f32(bits: np.ndarray, dtype: int) -> np.ndarray:
 
 def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b_dtype=capi.I4_PACKED,
                 lda=None, ldb=None, ldc=None, epilogue=capi.EPI_PASSTHROUGH, d0=None, d1=None,
-                k_batch=1, expect_kernel=None, b_layout=capi.COL_MAJOR, flags=0, use_workspace=True, ldd0=0, ldd1=0):
+                k_batch=1, expect_kernel=None, b_layout=capi.COL_MAJOR, flags=0, use_workspace=True, ldd0=0, ldd1=0,
+                scale_group_k=0, ld_scale=0):
     """Run one fpAintB GEMM through the C ABI; returns the (M, ldc) uint16 output bits."""
     a_t = dev(a_bits)
     b_t = b_dev_bytes if isinstance(b_dev_bytes, torch.Tensor) else dev(b_dev_bytes)
@@ -52,7 +53,8 @@ def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b
         a_t.data_ptr(), b_t.data_ptr(), s_t.data_ptr() if s_t is not None else None, c_t.data_ptr(), M, N, K,
         a_dtype=a_dtype, b_dtype=b_dtype, lda=lda, ldb=ldb, ldc=ldc, epilogue=epilogue,
         d0=d0_t.data_ptr() if d0_t is not None else None, d1=d1_t.data_ptr() if d1_t is not None else None,
-        k_batch=k_batch, b_layout=b_layout, flags=flags, ldd0=ldd0, ldd1=ldd1,
+        k_batch=k_batch, b_layout=b_layout, flags=flags, ldd0=ldd0, ldd1=ldd1, scale_group_k=scale_group_k,
+        ld_scale=ld_scale,
         c_dtype=(capi.F16 if a_dtype in (capi.F8_FNUZ, capi.F8_E4M3FN) else None))
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     if expect_kernel is not None:

@@ -221,3 +221,20 @@ def test_ck_factory_registrations_link():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "found 8 instances" in r.stdout, r.stdout + r.stderr
     assert r.stdout.count("DeviceGemmSplitK_WeightQuant_gfx950") == 4
+
+
+def test_group_wise_scale_validation_and_routes():
+    # groups of a multiple of 64 k: the matrix-core kernels; anything else: the general kernel
+    assert capi.kernel_name(_problem(scale_group_k=128)) == "wq_gemm_mfma_256"
+    assert "ScaleGroupK128" in capi.type_string(_problem(scale_group_k=128))
+    assert capi.kernel_name(_problem(M=512, N=512, scale_group_k=64)) == "wq_gemm_mfma_128"
+    assert capi.kernel_name(_problem(scale_group_k=32)) == "wq_gemm_generic"
+    assert capi.kernel_name(_problem(M=8, scale_group_k=128)) == "wq_gemm_mfma_128"     # no small-M kernel for groups yet
+    # the 256-tile kernel moves scale rows four bytes at a time: odd row strides stay on the 128-tile kernel
+    assert capi.kernel_name(_problem(scale_group_k=128, ld_scale=4097)) == "wq_gemm_mfma_128"
+    assert capi.kernel_name(_problem(scale_group_k=128, ld_scale=4104)) == "wq_gemm_mfma_256"
+    assert not capi.is_supported(_problem(scale_group_k=128, ld_scale=4000))            # shorter than a row of N scales
+    assert not capi.is_supported(_problem(scale_group_k=-1))
+    assert not capi.is_supported(_problem(scale_group_k=128, scale=None))
+    assert not capi.is_supported(_problem(scale_group_k=128, a_dtype=capi.BF16))        # fp16 activations only
+    assert b"fp16" in capi.lib.wqgemm_last_error()

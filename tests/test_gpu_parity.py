@@ -1090,6 +1090,35 @@ def test_torch_linear_over_packed_weights(tmp_path, bits, dt):
             fpaintb_linear(args["x"], args["weight"], args["scale"], args["bits"], args["epilogue"], args["bias"])
 
 
+def test_torch_linear_group_wise_scales(tmp_path):
+    """Group-wise quantised weights through the container and the torch operator: closer to the float weights than
+    per-channel scales on channels whose magnitude varies along k, and equal to a float64 matmul with the dequantised
+    weights within the fp16 bar."""
+    from composable_kernel_amd import weights
+    from composable_kernel_amd.torch_ops import WqLinear
+    rng = np.random.default_rng(128)
+    N, K, group_k = 512, 1024, 128
+    w = (rng.normal(0, 0.05, (N, K)) * np.linspace(0.2, 3.0, K)[None, :]).astype(np.float32)
+    q, s = weights.quantize_per_group(w, group_k, 4, "f16")
+    path = str(tmp_path / "grouped.npz")
+    weights.save_packed(path, weights.pack(q, s, 4, "f16", group_k))
+    pw = weights.load_packed(path)
+    lin = WqLinear(pw)
+    assert tuple(lin.scale.shape) == (K // group_k, N)
+    wd = torch.from_numpy(weights.dequantize(pw)).double()
+    for rows in (300, 5):
+        x = torch.from_numpy(rng.uniform(-1, 1, (rows, K)).astype(np.float32)).half()
+        y = lin(x.cuda())
+        assert torch.allclose(y.cpu().double(), x.double() @ wd.T, rtol=2e-3, atol=2e-3)
+    qc, sc = weights.quantize_per_channel(w, 4, "f16")
+    err_g = (wd - torch.from_numpy(w).double()).abs().mean()
+    err_c = (torch.from_numpy(weights.dequantize(weights.pack(qc, sc, 4, "f16"))).double() - torch.from_numpy(w).double()).abs().mean()
+    assert err_g < 0.8 * err_c
+    with pytest.raises((ValueError, TypeError, RuntimeError)):
+        lin.scale = lin.scale[:3].contiguous()       # 1024 is not a whole number of three groups
+        lin(x.cuda())
+
+
 def test_launch_is_graph_capturable(port):
     """wqgemm_launch neither allocates nor synchronises, so a stream capture can record it: a small-M problem with the
     planner's split-K (two kernels and a workspace) and a 256-tile problem are captured into one HIP graph, replayed

@@ -248,3 +248,22 @@ def test_bf16_i8_full_matrix_d_cases(port, golden_gemm):
     a = port.gemm_bf16_i8_dmat(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, K, 1, K, N, 3, g["bf16_d0"], 0)
     b = port.gemm_bf16_i8(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, K, 1, K, N, 3, g["bf16_d0"], g["bf16_d1"])
     np.testing.assert_array_equal(a, b)
+
+
+GROUPED_CASES = ("grp64_i4", "grp128_i4", "grp64_i8", "grp_ragged_i4", "grp128_int_i4")
+
+
+def test_grouped_scale_cases(port, golden_gemm):
+    """Group-wise weight scales: the checker against the reference's ReferencefpAintBGemm run on the (K, N) scale
+    tensor whose rows repeat per group (groups of 64 / 128 / 32 with a partial last group, padded scale rows)."""
+    g = golden_gemm
+    for tag in GROUPED_CASES:
+        M, N, K, lda, ldb, ldc, group_k, ld_scale = (int(v) for v in g[f"{tag}_shape"])
+        c = port.fpAintB_gemm_f16_grouped(g[f"{tag}_a"], g[f"{tag}_b"], g[f"{tag}_s"], M, N, K, lda, ldb, ldc, group_k,
+                                          ld_scale)
+        np.testing.assert_array_equal(c, g[f"{tag}_c"])
+    # one group spanning all of K is the per-channel GEMM
+    M, N, K, lda, ldb, ldc = (int(v) for v in g["fpaintb_real_shape"])
+    c = port.fpAintB_gemm_f16_grouped(g["fpaintb_real_a"], g["fpaintb_real_b"], g["fpaintb_real_s"][None, :], M, N, K,
+                                      lda, ldb, ldc, K, N)
+    np.testing.assert_array_equal(c, g["fpaintb_real_c"])

@@ -72,3 +72,14 @@ def test_i8_bias_requant_random(port, ref):
             for bs in (None, bias):
                 np.testing.assert_array_equal(port.gemm_i8_bias_requant(a, b, bs, M, N, K, K, K, N, rq, relu),
                                               ref.gemm_i8_bias_requant(a, b, bs, M, N, K, K, K, N, rq, relu))
+
+
+def test_grouped_scales_random(port, ref):
+    rng = np.random.default_rng(21)
+    for M, N, K, g in ((5, 12, 96, 32), (16, 40, 256, 64), (3, 8, 200, 128), (9, 16, 64, 1)):
+        groups = (K + g - 1) // g
+        a = rng.uniform(-1, 1, (M, K)).astype(np.float16).view(np.uint16)
+        b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        s = rng.uniform(2.0 ** -8, 2.0 ** -4, (groups, N + 4)).astype(np.float16).view(np.uint16)
+        np.testing.assert_array_equal(port.fpAintB_gemm_f16_grouped(a, b, s, M, N, K, K, K, N, g, N + 4),
+                                      ref.fpAintB_gemm_f16_grouped(a, b, s, M, N, K, K, K, N, g, N + 4))

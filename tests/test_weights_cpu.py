@@ -38,3 +38,40 @@ def test_container_rejects_foreign_files(tmp_path):
     np.savez(path, format=np.array("something-else"), weight=np.zeros(1))
     with pytest.raises(ValueError):
         weights.load_packed(path)
+
+
+@pytest.mark.parametrize("bits,group_k", [(4, 64), (4, 128), (8, 64)])
+def test_group_wise_quantize_pack_roundtrip(tmp_path, bits, group_k):
+    rng = np.random.default_rng(group_k + bits)
+    N, K = 24, 256
+    # channels whose magnitude changes along k: the case group-wise scales exist for
+    w = (rng.normal(0, 0.05, (N, K)) * np.linspace(0.2, 3.0, K)[None, :]).astype(np.float32)
+    q, s = weights.quantize_per_group(w, group_k, bits, "f16")
+    assert s.shape == (K // group_k, N) and q.shape == (N, K)
+    pw = weights.pack(q, s, bits, "f16", group_k)
+    deq = weights.dequantize(pw)
+    step = np.repeat(weights._from_bits(s, "f16").T, group_k, axis=1)
+    assert (np.abs(deq - w) <= 0.51 * step + np.abs(w) * 2.0 ** -10).all()
+    # finer than one scale per channel where the magnitudes differ
+    qc, sc = weights.quantize_per_channel(w, bits, "f16")
+    err_c = np.abs(weights.dequantize(weights.pack(qc, sc, bits, "f16")) - w)[:, : K // 4].mean()
+    assert np.abs(deq - w)[:, : K // 4].mean() < 0.7 * err_c
+    path = str(tmp_path / "g.npz")
+    weights.save_packed(path, pw)
+    back = weights.load_packed(path)
+    np.testing.assert_array_equal(back.weight, pw.weight)
+    np.testing.assert_array_equal(back.scale, pw.scale)
+    assert back.group_k == group_k
+    with pytest.raises(ValueError):
+        weights.pack(q, s[:-1], bits, "f16", group_k)
+    with pytest.raises(ValueError):
+        weights.quantize_per_group(w, 96, bits)
+
+
+def test_version_1_container_still_loads(tmp_path):
+    q = np.zeros((4, 16), np.int8)
+    path = str(tmp_path / "v1.npz")
+    np.savez(path, format=np.array("wqgemm-weights-1"), bits=np.array(8), scale_dtype=np.array("f16"), N=np.array(4),
+             K=np.array(16), weight=q, scale=np.full(4, 0x3C00, np.uint16))
+    pw = weights.load_packed(path)
+    assert pw.group_k == 0 and pw.scale.shape == (4,)

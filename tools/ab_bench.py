@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--a", default="f16", choices=["f16", "bf16", "f8", "f8fnuz"])
     ap.add_argument("--ramp", type=int, default=1000, help="untimed launches before timing (clock settling)")
     ap.add_argument("--b", default="i4", choices=["i4", "i8", "u8"])
+    ap.add_argument("--group-k", type=int, default=0, help="group-wise weight scales: k per group (fp16 activations)")
     args = ap.parse_args()
     M, N, K = args.M, args.N, args.K
     dev = torch.device("cuda", 0)
@@ -43,7 +44,8 @@ def main():
         d1 = torch.rand((M,), generator=g, device=dev)
     else:
         a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).to(adt)
-    s = (torch.rand((N,), generator=g, device=dev) * (2.0 ** -4 - 2.0 ** -8) + 2.0 ** -8).to(adt)
+    s_rows = K // args.group_k if args.group_k else 1
+    s = (torch.rand((s_rows, N), generator=g, device=dev) * (2.0 ** -4 - 2.0 ** -8) + 2.0 ** -8).to(adt)
     if args.b == "i4":
         q = torch.randint(-8, 8, (N, K), generator=g, device=dev, dtype=torch.int8)
         b = torch.empty((N, K // 2), dtype=torch.uint8, device=dev)
@@ -65,7 +67,8 @@ def main():
                                      d0=d0.data_ptr(), d1=d1.data_ptr(), flags=v)
         else:
             p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K,
-                                     a_dtype=capi.F16 if args.a == "f16" else capi.BF16, b_dtype=bdt, flags=v)
+                                     a_dtype=capi.F16 if args.a == "f16" else capi.BF16, b_dtype=bdt, flags=v,
+                                     scale_group_k=args.group_k)
         if not capi.is_supported(p):
             print(f"variant {v}: unsupported ({capi.lib.wqgemm_last_error().decode()})")
             continue
