@@ -4,9 +4,12 @@
 // with (library/src/tensor_operation_instance/gpu/gemm_multi_abd/*.cpp), implemented on this engine.  Linking this
 // file in place of CK's lets client_example/30_gemm_bf16Aint8B/*.cpp find the gfx950 operators unchanged.
 //
-// Not defined: ..._multiply_bf16_i8_bf16_mk_kn_mn_bias_v1_instances - its MultiplyAdd<bhalf_t, float, bhalf_t, bhalf_t>
-// (include/ck/tensor_operation/gpu/element/element_wise_operation.hpp:223-231) multiplies and adds the 16-bit
-// patterns as integers, and its declaration pairs one D layout with two D types.  Host code only.
+// Not defined: ..._multiply_bf16_i8_bf16_mk_kn_mn_bias_v1_instances.  Its declaration (gemm_multi_abd.hpp:198-209)
+// pairs ONE D layout with TWO D types, while the factory branch that calls it (gemm_multi_abd.hpp:585-625) passes a
+// vector of operators with two D layouts, so that branch cannot be instantiated in the reference either.  The operator
+// itself exists here -- DeviceGemmMultiABD_gfx950<Row, Row, Row, BF16, I8, BF16, false, MultiplyAdd> with the reference's
+// bit-pattern MultiplyAdd<bhalf_t, float, bhalf_t, bhalf_t> (element_wise_operation.hpp:200-231) -- and is reached by
+// direct instantiation.  Host code only.
 #include <memory>
 #include <vector>
 

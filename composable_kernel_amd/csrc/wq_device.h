@@ -270,6 +270,16 @@ __device__ __forceinline__ float load_d_as_f32(const void* d, int idx, int c_dty
     return (float)__builtin_bit_cast(_Float16, bits);
 }
 
+// MultiplyAdd<bhalf_t, float, bhalf_t, bhalf_t> (element_wise_operation.hpp:200-231): integer arithmetic on the 16-bit
+// patterns, low 16 bits kept.  Operands and result travel as the floats whose upper halves are those patterns, so the
+// truncating float -> bf16 store that follows returns the result bits unchanged.
+__device__ __forceinline__ float multiply_add_bf16_bits(float c, float d0, float d1)
+{
+    const uint32_t cb = __builtin_bit_cast(uint32_t, c) >> 16, a = __builtin_bit_cast(uint32_t, d0) >> 16,
+                   b  = __builtin_bit_cast(uint32_t, d1) >> 16;
+    return __builtin_bit_cast(float, (cb * a + b) << 16);
+}
+
 __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, int m, int n)
 {
     switch(e.kind)
@@ -295,6 +305,8 @@ __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, 
     case 7: return fast_gelu(x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
     case 8: return x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
     case 9: return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
+    case 13:
+        return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype), load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
     default: return x;
     }
 }
@@ -328,6 +340,8 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
         return x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
     else if constexpr(KIND == 9)
         return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
+    else if constexpr(KIND == 13)
+        return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype), load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
     else
         return x;
 }
@@ -337,6 +351,14 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
 template <int KIND>
 __device__ __forceinline__ f4_t apply_epilogue4(const EpilogueArgs& e, f4_t v, int m, int n)
 {
+    if constexpr(KIND == 13)
+    {
+        f4_t y;
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+            y[j] = apply_epilogue_k<13>(e, v[j], m, n + j);
+        return y;
+    }
     f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
     if constexpr(KIND == 2 || (KIND >= 6 && KIND <= 9))
     {
@@ -378,7 +400,7 @@ __device__ __forceinline__ f4_t load_d0_cols4(const EpilogueArgs& e, int n)
         const float* d = (const float*)e.d0 + n;
         return f4_t{d[0], d[1], d[2], d[3]};
     }
-    else if constexpr(KIND == 2 || (KIND >= 6 && KIND <= 9))
+    else if constexpr(KIND == 2 || KIND == 13 || (KIND >= 6 && KIND <= 9))
         return f4_t{load_d_as_f32(e.d0, n, e.c_dtype), load_d_as_f32(e.d0, n + 1, e.c_dtype),
                     load_d_as_f32(e.d0, n + 2, e.c_dtype), load_d_as_f32(e.d0, n + 3, e.c_dtype)};
     else
@@ -388,7 +410,7 @@ __device__ __forceinline__ f4_t load_d0_cols4(const EpilogueArgs& e, int n)
 template <int KIND>
 __device__ __forceinline__ f4_t load_d1_cols4(const EpilogueArgs& e, int n)
 {
-    if constexpr(KIND == 2)
+    if constexpr(KIND == 2 || KIND == 13)
         return f4_t{load_d_as_f32(e.d1, n, e.c_dtype), load_d_as_f32(e.d1, n + 1, e.c_dtype),
                     load_d_as_f32(e.d1, n + 2, e.c_dtype), load_d_as_f32(e.d1, n + 3, e.c_dtype)};
     else
@@ -407,6 +429,9 @@ __device__ __forceinline__ float load_d1_row(const EpilogueArgs& e, int m)
 template <int KIND>
 __device__ __forceinline__ f4_t apply_epilogue4_bcast(f4_t v, f4_t d0, f4_t d1n, float d1m)
 {
+    if constexpr(KIND == 13)
+        return f4_t{multiply_add_bf16_bits(v[0], d0[0], d1n[0]), multiply_add_bf16_bits(v[1], d0[1], d1n[1]),
+                    multiply_add_bf16_bits(v[2], d0[2], d1n[2]), multiply_add_bf16_bits(v[3], d0[3], d1n[3])};
     f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
     if constexpr(KIND == 6 || KIND == 7)
         lo = lo + f2_t{d0[0], d0[1]}, hi = hi + f2_t{d0[2], d0[3]};

@@ -506,10 +506,11 @@ struct DeviceGemmMultiABD_WeightQuant_gfx950
 //   ScaleOnB = true : Bs = (B0 int8, B1 scale[N]), BOp = Multiply;   CDE = PassThrough | FastGelu (no D),
 //                                                                     Add | AddFastGelu (D0 = bias[N])
 //   ScaleOnB = false: Bs = (B0 int8),              BOp = PassThrough; CDE = Multiply | MultiplyFastGelu
-//                                                                     (D0 = scale[N]), MultiplyAddFastGelu
+//                                                                     (D0 = scale[N]), MultiplyAddFastGelu | MultiplyAdd
 //                                                                     (D0 = scale[N], D1 = bias[N])
-// D tensors have lengths (M, N) and stride 0 along M: N values of E's type.  (The reference's MultiplyAdd for bhalf_t,
-// element_wise_operation.hpp:223-231, multiplies and adds the 16-bit patterns as integers; it is not offered.)
+// D tensors have lengths (M, N) and stride 0 along M: N values of E's type, or a row pitch for full matrices.
+// (The reference's MultiplyAdd for bhalf_t, element_wise_operation.hpp:200-231, multiplies and adds the 16-bit patterns
+// as integers; it is reproduced as written.)
 // ---------------------------------------------------------------------------------------------
 namespace wq_detail {
 template <typename T, int N>
@@ -555,13 +556,17 @@ constexpr int multi_abd_epilogue()
             return WQ_EPI_MULTIPLY_FASTGELU;
         else if constexpr(std::is_same_v<CDE, ew::MultiplyAddFastGelu>)
             return WQ_EPI_MULTIPLY_ADD_FASTGELU;
+        else if constexpr(std::is_same_v<CDE, ew::MultiplyAdd>)
+            return WQ_EPI_MULTIPLY_ADD;
         else
             return -1;
     }
 }
 constexpr int num_d_of(int epilogue)
 {
-    return epilogue == WQ_EPI_PASSTHROUGH || epilogue == WQ_EPI_FASTGELU ? 0 : (epilogue == WQ_EPI_MULTIPLY_ADD_FASTGELU ? 2 : 1);
+    return epilogue == WQ_EPI_PASSTHROUGH || epilogue == WQ_EPI_FASTGELU
+               ? 0
+               : (epilogue == WQ_EPI_MULTIPLY_ADD_FASTGELU || epilogue == WQ_EPI_MULTIPLY_ADD ? 2 : 1);
 }
 } // namespace wq_detail
 

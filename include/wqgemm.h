@@ -66,7 +66,12 @@ typedef enum wq_epilogue
      *  example/14_gemm_quantization/gemm_xdl_bias_relu_quantization_int8.cpp:30-32,223-229) */
     WQ_EPI_RELU_MUL_CLAMP             = 10, /* Activation_Mul_Clamp<Relu>                                  */
     WQ_EPI_ADD_ACT_MUL_CLAMP          = 11, /* Add_Activation_Mul_Clamp<PassThrough>: int32 d0[n]          */
-    WQ_EPI_ADD_RELU_MUL_CLAMP         = 12  /* Add_Activation_Mul_Clamp<Relu>: int32 d0[n]                 */
+    WQ_EPI_ADD_RELU_MUL_CLAMP         = 12, /* Add_Activation_Mul_Clamp<Relu>: int32 d0[n]                 */
+    /* element_wise_operation.hpp:200-231, the bhalf_t specialisation MultiplyAdd<bhalf_t, float, bhalf_t, bhalf_t> of
+     * the multi-ABD "multiply ... bias" instance (gemm_multi_abd.hpp:198-209): "type_convert<bhalf_t>(c) * d0 + d1" with
+     * bhalf_t = unsigned short, i.e. integer arithmetic on the three 16-bit patterns, low 16 bits kept.  Reproduced
+     * bit for bit; bf16 C only; d0, d1 of C's type. */
+    WQ_EPI_MULTIPLY_ADD               = 13
 } wq_epilogue;
 
 /* wqgemm_problem.flags */

@@ -253,6 +253,20 @@ struct MultiplyMultiply
     }
 };
 
+// element_wise_operation.hpp:200-231.  The reference specialises it per type tuple; for bhalf_t outputs and operands
+// "type_convert<bhalf_t>(c) * d0 + d1" runs on unsigned short, i.e. on the bit patterns -- kept as written.
+struct MultiplyAdd
+{
+    template <typename E, typename C, typename D0, typename D1>
+    void operator()(E& e, const C& c, const D0& d0, const D1& d1) const
+    {
+        if constexpr(std::is_same_v<E, bhalf_t> && std::is_same_v<D0, bhalf_t> && std::is_same_v<D1, bhalf_t>)
+            e = static_cast<bhalf_t>(static_cast<unsigned>(ck::type_convert<bhalf_t>(c)) * d0 + d1);
+        else
+            e = ck::type_convert<E>(ck::type_convert<float>(c) * ck::type_convert<float>(d0) + ck::type_convert<float>(d1));
+    }
+};
+
 struct MultiplyAddFastGelu
 {
     template <typename E, typename C, typename D0, typename D1>

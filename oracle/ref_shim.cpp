@@ -131,6 +131,13 @@ uint16_t ckref_multiply_add_fastgelu_bf16(float c, uint16_t d0, uint16_t d1)
     ew::MultiplyAddFastGelu{}(e, c, bhalf_t(d0), bhalf_t(d1));
     return e;
 }
+// element_wise_operation.hpp:200-231 (the bhalf_t specialisation)
+uint16_t ckref_multiply_add_bf16(float c, uint16_t d0, uint16_t d1)
+{
+    bhalf_t e;
+    ew::MultiplyAdd{}(e, c, bhalf_t(d0), bhalf_t(d1));
+    return e;
+}
 
 // ---- input generators (fill.hpp:18-86, host_tensor_generator.hpp:84-169) -------------------
 // dtype: 0 = half, 1 = bhalf, 2 = int8, 3 = float
@@ -290,6 +297,8 @@ void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1,
                 ew::AddFastGelu{}(y, tc(m, n), bhalf_t(d0[n]));
             else if(epilogue == 5)
                 ew::Multiply{}(y, tc(m, n), bhalf_t(d0[n]));
+            else if(epilogue == 7)
+                ew::MultiplyAdd{}(y, tc(m, n), bhalf_t(d0[n]), bhalf_t(d1[n]));
             else
                 ew::MultiplyFastGelu{}(y, tc(m, n), bhalf_t(d0[n]));
             e[static_cast<size_t>(m) * lde + n] = y;
@@ -337,6 +346,8 @@ void ckref_gemm_bf16_i8_dmat(const uint16_t* a, const int8_t* b0, const uint16_t
                 ew::AddFastGelu{}(y, tc(m, n), td0(m, n));
             else if(epilogue == 5)
                 ew::Multiply{}(y, tc(m, n), td0(m, n));
+            else if(epilogue == 7)
+                ew::MultiplyAdd{}(y, tc(m, n), td0(m, n), td1(m, n));
             else
                 ew::MultiplyFastGelu{}(y, tc(m, n), td0(m, n));
             e[static_cast<size_t>(m) * lde + n] = y;

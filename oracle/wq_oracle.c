@@ -211,6 +211,14 @@ uint16_t wqo_multiply_add_fastgelu_bf16(float c, uint16_t d0, uint16_t d1)
     return wqo_f32_to_bf16(wqo_fastgelu(x0));
 }
 
+/* element_wise_operation.hpp:200-231  MultiplyAdd<bhalf,float,bhalf,bhalf>: "type_convert<bhalf_t>(c) * d0 + d1" with
+ * bhalf_t = unsigned short, i.e. INTEGER arithmetic on the three 16-bit patterns, truncated to 16 bits on assignment
+ * (the low 16 bits do not depend on how the 32-bit product wraps).  Reproduced as written. */
+uint16_t wqo_multiply_add_bf16(float c, uint16_t d0, uint16_t d1)
+{
+    return (uint16_t)((uint32_t)wqo_f32_to_bf16(c) * (uint32_t)d0 + (uint32_t)d1);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* input generators                                                                            */
 /* ------------------------------------------------------------------------------------------- */
@@ -500,6 +508,7 @@ void wqo_gemm_i8_bias_requant(const int8_t* a, const int8_t* b, const int32_t* b
  *            4 AddFastGelu<bhalf,float,bhalf>         binary_element_wise_operation.hpp:511-522
  *            5 Multiply<bhalf>(float, bhalf)          binary_element_wise_operation.hpp:180-188
  *            6 MultiplyFastGelu<bhalf,float,bhalf>    binary_element_wise_operation.hpp:578-590
+ *            7 MultiplyAdd<bhalf,float,bhalf,bhalf>   element_wise_operation.hpp:200-231 (d0, d1; bit-pattern arithmetic)
  *   b1 == NULL: the "multiply" instances, B = PassThrough(b0) (int8 -> bhalf, exact), scale in the epilogue.
  * B element (k,n) at k*b_sk + n*b_sn.  D element (m,n) at m*ldd + n: the examples' d_m_n(m, n) over a row-major
  * descriptor with row stride StrideD (gemm_multi_ABD_xdl_bias_fastgelu_bf16_i8.cpp:86,140,263), 0 = one value per
@@ -541,6 +550,8 @@ static void bf16_i8_mn(void* p, int m, int n)
         y = wqo_f32_to_bf16(wqo_fastgelu(acc + wqo_bf16_to_f32(d0[n])));
     else if(x->epilogue == 5)
         y = wqo_f32_to_bf16(acc * wqo_bf16_to_f32(d0[n]));
+    else if(x->epilogue == 7)
+        y = wqo_multiply_add_bf16(acc, d0[n], d1[n]);
     else
         y = wqo_f32_to_bf16(wqo_fastgelu(acc * wqo_bf16_to_f32(d0[n])));
     x->e[(size_t)m * x->lde + n] = y;

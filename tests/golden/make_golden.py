@@ -232,6 +232,20 @@ def gemm_cases(ref) -> dict:
     grouped("grp64_i8", 32, 48, 128, 128, 128, 48, 64, 48, -128, 127)
     grouped("grp_ragged_i4", 33, 20, 80, 88, 96, 24, 32, 20, -8, 7)
     grouped("grp128_int_i4", 128, 128, 512, 512, 512, 128, 128, 128, -8, 7, integer=True)
+
+    # ---- MultiplyAdd<bhalf, float, bhalf, bhalf> (element_wise_operation.hpp:200-231: integer arithmetic on the 16-bit
+    # patterns) on the bf16 x int8 case above: the "multiply" instance form (row-major B, no B scale), per-column and
+    # full-matrix D operands; and a table of the functor itself
+    M, N, K = 48, 64, 128
+    brow = np.ascontiguousarray(out["bf16_bcol"].T)
+    out["bf16_mul_e_row_ep7"] = ref.gemm_bf16_i8(out["bf16_a"], brow, None, M, N, K, K, N, 1, N, 7, out["bf16_s"], out["bf16_d1"])
+    out["bf16_dmat_e_row_ep7"] = ref.gemm_bf16_i8_dmat(out["bf16_a"], brow, None, M, N, K, K, N, 1, N, 7, out["bf16_dm0"], N,
+                                                       out["bf16_dm1"], N + 8)
+    mc = rng.uniform(-300, 300, 512).astype(np.float32)
+    md0 = rng.integers(0, 65536, 512).astype(np.uint16)
+    md1 = rng.integers(0, 65536, 512).astype(np.uint16)
+    out["mad_c"], out["mad_d0"], out["mad_d1"] = mc, md0, md1
+    out["mad_e"] = np.array([ref.multiply_add_bf16(float(c), int(a), int(b)) for c, a, b in zip(mc, md0, md1)], np.uint16)
     return out
 
 

@@ -199,6 +199,39 @@ def test_bf16_int8_multi_abd_family_mfma(port):
             check_err(bits_to_f32(got, capi.BF16), bits_to_f32(exp, capi.BF16), 1e-2, 1e-3)
 
 
+def test_bf16_multiply_add_bit_pattern_epilogue(golden_gemm, port):
+    """MultiplyAdd<bhalf_t, float, bhalf_t, bhalf_t> (element_wise_operation.hpp:200-231): integer arithmetic on the
+    16-bit patterns.  Goldens from the reference functor bit for bit on the general kernel (per-column and full-matrix
+    D operands); the tile, small-M and split-K paths on integer-valued inputs, where the accumulator -- and with it the
+    bit pattern the functor multiplies -- does not depend on the summation order."""
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    brow = np.ascontiguousarray(g["bf16_bcol"].T)
+    got = run_fpaintb(g["bf16_a"], brow, None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=capi.EPI_MULTIPLY_ADD,
+                      d0=g["bf16_s"], d1=g["bf16_d1"], b_layout=capi.ROW_MAJOR, ldb=N, expect_kernel=GENERIC)
+    np.testing.assert_array_equal(got, g["bf16_mul_e_row_ep7"].reshape(M, N))
+    got = run_fpaintb(g["bf16_a"], brow, None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=capi.EPI_MULTIPLY_ADD,
+                      d0=g["bf16_dm0"], d1=g["bf16_dm1"], ldd0=N, ldd1=N + 8, b_layout=capi.ROW_MAJOR, ldb=N,
+                      expect_kernel=GENERIC)
+    np.testing.assert_array_equal(got, g["bf16_dmat_e_row_ep7"].reshape(M, N))
+    rng = np.random.default_rng(13)
+    for (M, N, K, flags, kern, kb) in ((256, 256, 192, capi.FLAG_TILE_128, MFMA, 1), (300, 256, 192, capi.FLAG_TILE_256, MFMA256, 1),
+                                       (256, 256, 256, capi.FLAG_TILE_256, MFMA256, 2), (24, 128, 256, 0, "wq_gemm_skinny", 1),
+                                       (8, 2048, 512, 0, "wq_gemm_skinny_ws", 1)):
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        a = bf16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+        d0 = rng.integers(0, 65536, N).astype(np.uint16)          # any bit patterns: the functor treats them as integers
+        d1 = rng.integers(0, 65536, N).astype(np.uint16)
+        got = run_fpaintb(a, q, None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=capi.EPI_MULTIPLY_ADD, d0=d0, d1=d1,
+                          flags=flags, k_batch=kb, expect_kernel=kern)
+        exp = port.gemm_bf16_i8(a, q, None, M, N, K, K, 1, K, N, 7, d0, d1).reshape(M, N)
+        np.testing.assert_array_equal(got, exp)
+    # fp16 outputs have no such functor in the engine
+    p = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, 256, 256, 256, a_dtype=capi.F16, b_dtype=capi.I8,
+                             epilogue=capi.EPI_MULTIPLY_ADD, d0=1 << 20, d1=1 << 20)
+    assert not capi.is_supported(p)
+
+
 @pytest.mark.parametrize("a_dtype", [capi.F16, capi.BF16])
 def test_row_major_b_via_transpose(port, a_dtype):
     """8-bit weights stored (K, N) row-major: with a workspace the launch transposes them and runs the matrix-core

@@ -267,3 +267,17 @@ def test_grouped_scale_cases(port, golden_gemm):
     c = port.fpAintB_gemm_f16_grouped(g["fpaintb_real_a"], g["fpaintb_real_b"], g["fpaintb_real_s"][None, :], M, N, K,
                                       lda, ldb, ldc, K, N)
     np.testing.assert_array_equal(c, g["fpaintb_real_c"])
+
+
+def test_multiply_add_bit_pattern(port, golden_gemm):
+    """MultiplyAdd<bhalf_t, float, bhalf_t, bhalf_t>: the reference functor on random operands and inside the bf16 x int8
+    GEMM ("multiply" instance form, per-column and full-matrix D)."""
+    g = golden_gemm
+    for c, a, b, e in zip(g["mad_c"], g["mad_d0"], g["mad_d1"], g["mad_e"]):
+        assert port.multiply_add_bf16(float(c), int(a), int(b)) == int(e)
+    M, N, K = 48, 64, 128
+    brow = np.ascontiguousarray(g["bf16_bcol"].T)
+    e = port.gemm_bf16_i8(g["bf16_a"], brow, None, M, N, K, K, N, 1, N, 7, g["bf16_s"], g["bf16_d1"])
+    np.testing.assert_array_equal(e, g["bf16_mul_e_row_ep7"])
+    e = port.gemm_bf16_i8_dmat(g["bf16_a"], brow, None, M, N, K, K, N, 1, N, 7, g["bf16_dm0"], N, g["bf16_dm1"], N + 8)
+    np.testing.assert_array_equal(e, g["bf16_dmat_e_row_ep7"])
