@@ -37,7 +37,7 @@ FLAG_PINGPONG = 8192
 
 # every symbol include/wqgemm.h declares
 EXPORTS = (
-    "wqgemm_version", "wqgemm_last_error", "wqgemm_is_supported", "wqgemm_workspace_bytes",
+    "wqgemm_version", "wqgemm_problem_size", "wqgemm_last_error", "wqgemm_is_supported", "wqgemm_workspace_bytes",
     "wqgemm_launch", "wqgemm_run_timed", "wqgemm_type_string", "wqgemm_kernel_name",
     "wqgemm_pack_int4", "wqgemm_pack_int4_host", "wqgemm_reduce_finalize", "wqgemm_splitk_kread",
     "wqgemm_run_timed_rotating", "wqgemm_launch_noalloc", "wqgemm_splitk_multi_workspace_bytes",
@@ -75,6 +75,10 @@ def _load() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     P = C.POINTER(Problem)
     L.wqgemm_version.restype = C.c_char_p
+    L.wqgemm_problem_size.restype = C.c_size_t
+    if L.wqgemm_problem_size() != C.sizeof(Problem):
+        raise ImportError(f"{LIB_PATH}: built with a wqgemm_problem of {L.wqgemm_problem_size()} bytes, this binding "
+                          f"describes {C.sizeof(Problem)}: rebuild the library (make -C composable_kernel_amd/csrc)")
     L.wqgemm_last_error.restype = C.c_char_p
     L.wqgemm_is_supported.restype = C.c_int
     L.wqgemm_is_supported.argtypes = [P]

@@ -704,6 +704,8 @@ extern "C" {
 
 const char* wqgemm_version(void) { return "wqgemm 0.1 (gfx950)"; }
 
+size_t wqgemm_problem_size(void) { return sizeof(wqgemm_problem); }
+
 const char* wqgemm_last_error(void) { return g_err; }
 
 int32_t wqgemm_splitk_kread(int32_t K, int32_t k_batch, int32_t granule)

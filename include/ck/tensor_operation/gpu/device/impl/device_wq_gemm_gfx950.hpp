@@ -150,6 +150,9 @@ inline bool device_is_gfx950()
 
 inline bool supported(const wqgemm_problem& prob)
 {
+    // a client compiled against another release of include/wqgemm.h than the library it found at run time
+    if(wqgemm_problem_size() != sizeof(wqgemm_problem))
+        throw std::runtime_error("libwqgemm.so and include/wqgemm.h disagree on sizeof(wqgemm_problem): rebuild the client");
     if(!device_is_gfx950())
     {
         std::cout << "DeviceOp err: Arch" << std::endl; // the reference's wording for a wrong target

@@ -140,6 +140,12 @@ typedef struct wqgemm_problem
 /* Library version string, e.g. "wqgemm 0.1 (gfx950)". */
 const char* wqgemm_version(void);
 
+/* sizeof(wqgemm_problem) as the library was built with.  wqgemm_problem grows at its end from release to release;
+ * a caller compiled against another header must not hand its struct over (the library would read fields the caller
+ * never wrote).  Bindings compare this with their own size when they load the library.  No counterpart in the
+ * reference, whose Argument objects never cross a library boundary. */
+size_t wqgemm_problem_size(void);
+
 /* Message of the last failure on the calling thread ("" if none). */
 const char* wqgemm_last_error(void);
 

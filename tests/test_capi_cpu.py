@@ -238,3 +238,8 @@ def test_group_wise_scale_validation_and_routes():
     assert not capi.is_supported(_problem(scale_group_k=128, scale=None))
     assert not capi.is_supported(_problem(scale_group_k=128, a_dtype=capi.BF16))        # fp16 activations only
     assert b"fp16" in capi.lib.wqgemm_last_error()
+
+
+def test_problem_struct_size_handshake():
+    # the binding refuses a library built with another wqgemm_problem (it checks at load time); here: they agree
+    assert capi.lib.wqgemm_problem_size() == C.sizeof(capi.Problem)
