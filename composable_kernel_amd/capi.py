@@ -33,7 +33,7 @@ FLAG_PINGPONG = 8192
 # wq_epilogue
 (EPI_PASSTHROUGH, EPI_FASTGELU, EPI_MULTIPLY_ADD_FASTGELU, EPI_MULTIPLY_MULTIPLY,
  EPI_MULTIPLY_MULTIPLY_FASTGELU, EPI_ACT_MUL_CLAMP, EPI_ADD, EPI_ADD_FASTGELU, EPI_MULTIPLY,
- EPI_MULTIPLY_FASTGELU, EPI_RELU_MUL_CLAMP, EPI_ADD_ACT_MUL_CLAMP, EPI_ADD_RELU_MUL_CLAMP, EPI_MULTIPLY_ADD) = range(14)
+ EPI_MULTIPLY_FASTGELU, EPI_RELU_MUL_CLAMP, EPI_ADD_ACT_MUL_CLAMP, EPI_ADD_RELU_MUL_CLAMP, EPI_MULTIPLY_ADD, EPI_CONVERT_BF16_RTN) = range(15)
 
 # every symbol include/wqgemm.h declares
 EXPORTS = (

@@ -280,6 +280,17 @@ __device__ __forceinline__ float multiply_add_bf16_bits(float c, float d0, float
     return __builtin_bit_cast(float, (cb * a + b) << 16);
 }
 
+// ConvertBF16RTN (unary_element_wise_operation.hpp:236-251 -> type_convert.hpp:507-549): round to nearest even on the
+// upper 16 bits; Inf / NaN patterns are not incremented, a NaN whose payload sits in the lower half keeps a mantissa
+// bit.  Returned as the float whose upper half is the result, for the truncating float -> bf16 store that follows.
+__device__ __forceinline__ float convert_bf16_rtn_bits(float x)
+{
+    uint32_t u        = __builtin_bit_cast(uint32_t, x);
+    const bool finite = (~u & 0x7F800000u) != 0;
+    u                 = finite ? u + 0x7FFFu + ((u >> 16) & 1u) : ((u & 0xFFFFu) ? (u | 0x10000u) : u);
+    return __builtin_bit_cast(float, u & 0xFFFF0000u);
+}
+
 __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, int m, int n)
 {
     switch(e.kind)
@@ -307,6 +318,7 @@ __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, 
     case 9: return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
     case 13:
         return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype), load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
+    case 14: return convert_bf16_rtn_bits(x);
     default: return x;
     }
 }
@@ -342,6 +354,8 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
         return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
     else if constexpr(KIND == 13)
         return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype), load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
+    else if constexpr(KIND == 14)
+        return convert_bf16_rtn_bits(x);
     else
         return x;
 }
@@ -351,12 +365,12 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
 template <int KIND>
 __device__ __forceinline__ f4_t apply_epilogue4(const EpilogueArgs& e, f4_t v, int m, int n)
 {
-    if constexpr(KIND == 13)
+    if constexpr(KIND == 13 || KIND == 14)
     {
         f4_t y;
 #pragma unroll
         for(int j = 0; j < 4; ++j)
-            y[j] = apply_epilogue_k<13>(e, v[j], m, n + j);
+            y[j] = apply_epilogue_k<KIND>(e, v[j], m, n + j);
         return y;
     }
     f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
@@ -432,6 +446,9 @@ __device__ __forceinline__ f4_t apply_epilogue4_bcast(f4_t v, f4_t d0, f4_t d1n,
     if constexpr(KIND == 13)
         return f4_t{multiply_add_bf16_bits(v[0], d0[0], d1n[0]), multiply_add_bf16_bits(v[1], d0[1], d1n[1]),
                     multiply_add_bf16_bits(v[2], d0[2], d1n[2]), multiply_add_bf16_bits(v[3], d0[3], d1n[3])};
+    if constexpr(KIND == 14)
+        return f4_t{convert_bf16_rtn_bits(v[0]), convert_bf16_rtn_bits(v[1]), convert_bf16_rtn_bits(v[2]),
+                    convert_bf16_rtn_bits(v[3])};
     f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
     if constexpr(KIND == 6 || KIND == 7)
         lo = lo + f2_t{d0[0], d0[1]}, hi = hi + f2_t{d0[2], d0[3]};

@@ -41,12 +41,19 @@ int WQ_CAT(WQ_INST_AK, WQ_INST_BK)(const GemmParams& gp, dim3 grid, hipStream_t 
     const bool w2x4 = variant & WQ_FLAG_WAVES_2X4;
 #if WQ_INST_AK == 0 && WQ_INST_BK == 0
     if(gp.dbg) // diagnostic stamped builds (default wave grid only)
+#ifdef WQ_INST_MINIMAL
+        return launch_v<AK, BK, 1, 5, true>(gp, grid, s);
+#else
         return (variant & WQ_FLAG_DEQUANT_IN_L) ? launch_v<AK, BK, 1, 2, true>(gp, grid, s)
                                                  : launch_v<AK, BK, 1, 5, true>(gp, grid, s);
 #endif
-#if WQ_INST_AK == 0
+#endif
+#if WQ_INST_AK == 0 && !defined(WQ_INST_MINIMAL)
     if(gp.scale_group_k > 0) // group-wise scales: the default schedule and wave grid only
         return launch_v<AK, BK, 1, 5, false, true>(gp, grid, s);
+#endif
+#ifdef WQ_INST_MINIMAL // tuning builds: the default schedule only (a third of the compile time)
+    return launch_v<AK, BK, 1, 5, false>(gp, grid, s);
 #endif
     if(variant & WQ_FLAG_LOCKSTEP)
         return launch_v<AK, BK, 2, 0, false>(gp, grid, s);

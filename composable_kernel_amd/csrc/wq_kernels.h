@@ -125,6 +125,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
     case 13: // (bf16 outputs only: checked on the host)
         tile_epilogue_k<13, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
+    case 14: // (bf16 outputs only)
+        tile_epilogue_k<14, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
+        break;
     default:
         bf ? tile_epilogue_k<0, true, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq) : tile_epilogue_k<0, false, NT, MT, RSTEP, CSTEP>(p, acc, m_base, n_base, fr, fq);
         break;
@@ -273,6 +276,9 @@ __device__ __forceinline__ void tile256_epilogue(const GemmParams& p, const f4_t
         WQ_EPI_CASE(9)
     case 13: // (bf16 outputs only: checked on the host)
         tile256_epilogue_lds_k<13, true, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);
+        break;
+    case 14: // (bf16 outputs only)
+        tile256_epilogue_lds_k<14, true, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane);
         break;
     default:
         bf ? tile256_epilogue_lds_k<0, true, NT, MT, RSTEP, CSTEP>(p, acc, lds, m0, n0, row_w, col_w, fr, fq, wave, lane)

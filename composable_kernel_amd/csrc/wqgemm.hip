@@ -93,6 +93,10 @@ int check_fp_epilogue(const wqgemm_problem* p)
     {
     case WQ_EPI_PASSTHROUGH:
     case WQ_EPI_FASTGELU: break;
+    case WQ_EPI_CONVERT_BF16_RTN:
+        if(p->c_dtype != WQ_BF16)
+            return fail(WQ_ERR_UNSUPPORTED, "ConvertBF16RTN produces bf16 outputs only");
+        break;
     case WQ_EPI_MULTIPLY_ADD:
         if(p->c_dtype != WQ_BF16)
             return fail(WQ_ERR_UNSUPPORTED, "the bit-pattern MultiplyAdd epilogue exists for bf16 outputs only");

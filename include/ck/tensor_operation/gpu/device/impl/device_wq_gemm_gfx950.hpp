@@ -506,7 +506,7 @@ struct DeviceGemmMultiABD_WeightQuant_gfx950
 // ---------------------------------------------------------------------------------------------
 // The whole multi-ABD instance family of the reference for weight-quantized B
 // (library/include/ck/library/tensor_operation_instance/gpu/gemm_multi_abd.hpp:24-260):
-//   ScaleOnB = true : Bs = (B0 int8, B1 scale[N]), BOp = Multiply;   CDE = PassThrough | FastGelu (no D),
+//   ScaleOnB = true : Bs = (B0 int8, B1 scale[N]), BOp = Multiply;   CDE = PassThrough | FastGelu | ConvertBF16RTN (no D),
 //                                                                     Add | AddFastGelu (D0 = bias[N])
 //   ScaleOnB = false: Bs = (B0 int8),              BOp = PassThrough; CDE = Multiply | MultiplyFastGelu
 //                                                                     (D0 = scale[N]), MultiplyAddFastGelu | MultiplyAdd
@@ -548,12 +548,16 @@ constexpr int multi_abd_epilogue()
             return WQ_EPI_ADD;
         else if constexpr(std::is_same_v<CDE, ew::AddFastGelu>)
             return WQ_EPI_ADD_FASTGELU;
+        else if constexpr(std::is_same_v<CDE, ew::ConvertBF16RTN>)
+            return WQ_EPI_CONVERT_BF16_RTN;
         else
             return -1;
     }
     else
     {
-        if constexpr(std::is_same_v<CDE, ew::Multiply>)
+        if constexpr(std::is_same_v<CDE, ew::ConvertBF16RTN>) // unscaled int8 weights, nearest-even bf16 output
+            return WQ_EPI_CONVERT_BF16_RTN;
+        else if constexpr(std::is_same_v<CDE, ew::Multiply>)
             return WQ_EPI_MULTIPLY;
         else if constexpr(std::is_same_v<CDE, ew::MultiplyFastGelu>)
             return WQ_EPI_MULTIPLY_FASTGELU;
@@ -567,7 +571,7 @@ constexpr int multi_abd_epilogue()
 }
 constexpr int num_d_of(int epilogue)
 {
-    return epilogue == WQ_EPI_PASSTHROUGH || epilogue == WQ_EPI_FASTGELU
+    return epilogue == WQ_EPI_PASSTHROUGH || epilogue == WQ_EPI_FASTGELU || epilogue == WQ_EPI_CONVERT_BF16_RTN
                ? 0
                : (epilogue == WQ_EPI_MULTIPLY_ADD_FASTGELU || epilogue == WQ_EPI_MULTIPLY_ADD ? 2 : 1);
 }

@@ -71,7 +71,11 @@ typedef enum wq_epilogue
      * the multi-ABD "multiply ... bias" instance (gemm_multi_abd.hpp:198-209): "type_convert<bhalf_t>(c) * d0 + d1" with
      * bhalf_t = unsigned short, i.e. integer arithmetic on the three 16-bit patterns, low 16 bits kept.  Reproduced
      * bit for bit; bf16 C only; d0, d1 of C's type. */
-    WQ_EPI_MULTIPLY_ADD               = 13
+    WQ_EPI_MULTIPLY_ADD               = 13,
+    /* unary_element_wise_operation.hpp:236-251 ConvertBF16RTN -> type_convert.hpp:507-549 bf16_convert_rtn<bhalf_t, float>:
+     * the accumulator leaves as bf16 rounded to nearest even instead of truncated (Inf / NaN patterns kept as the
+     * reference keeps them); the C operation of example/01_gemm/gemm_xdl_bf16_rtn.cpp:21.  bf16 C only; no D operand. */
+    WQ_EPI_CONVERT_BF16_RTN           = 14
 } wq_epilogue;
 
 /* wqgemm_problem.flags */

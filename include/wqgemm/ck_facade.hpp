@@ -24,6 +24,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -182,6 +183,26 @@ struct Relu
     void operator()(T& y, const T& x) const
     {
         y = x > T(0) ? x : T(0);
+    }
+};
+
+// unary_element_wise_operation.hpp:236-251: float -> bhalf_t rounded to nearest even (type_convert.hpp:507-549) instead
+// of type_convert's truncation; Inf / NaN patterns are not incremented, a NaN with its payload in the lower half keeps
+// a mantissa bit.
+struct ConvertBF16RTN
+{
+    template <typename Y, typename X>
+    void operator()(Y& y, const X& x) const
+    {
+        static_assert(std::is_same_v<Y, bhalf_t>, "ConvertBF16RTN produces bhalf_t");
+        const float f = ck::type_convert<float>(x);
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        if(~u & 0x7F800000u)
+            u += 0x7FFFu + ((u >> 16) & 1u);
+        else if(u & 0xFFFFu)
+            u |= 0x10000u;
+        y = static_cast<bhalf_t>(u >> 16);
     }
 };
 

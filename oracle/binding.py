@@ -76,6 +76,7 @@ class Checker:
         self.multiply_multiply_f16 = sig("multiply_multiply_f16", C.c_uint16, [C.c_float] * 3)
         self.multiply_multiply_bf16 = sig("multiply_multiply_bf16", C.c_uint16, [C.c_float] * 3)
         self.multiply_add_bf16 = sig("multiply_add_bf16", C.c_uint16, [C.c_float, C.c_uint16, C.c_uint16])
+        self.bf16_convert_rtn = sig("bf16_convert_rtn", C.c_uint16, [C.c_float])
         self.multiply_add_fastgelu_bf16 = sig(
             "multiply_add_fastgelu_bf16", C.c_uint16, [C.c_float, C.c_uint16, C.c_uint16])
         self._fill = sig("fill_uniform", None, [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int])

@@ -139,6 +139,14 @@ uint16_t ckref_multiply_add_bf16(float c, uint16_t d0, uint16_t d1)
     return e;
 }
 
+// unary_element_wise_operation.hpp:236-251 -> type_convert.hpp:507-549
+uint16_t ckref_bf16_convert_rtn(float x)
+{
+    bhalf_t e;
+    ew::ConvertBF16RTN{}(e, x);
+    return e;
+}
+
 // ---- input generators (fill.hpp:18-86, host_tensor_generator.hpp:84-169) -------------------
 // dtype: 0 = half, 1 = bhalf, 2 = int8, 3 = float
 void ckref_fill_uniform(void* out, size_t n, int dtype, float a, float b, int integer_value)
@@ -258,7 +266,8 @@ void ckref_gemm_i8_bias_requant(const int8_t* a, const int8_t* b, const int32_t*
 // bhalf, float, float, PT,PT,PT>; e = epilogue(c).  B element (k,n) at k*b_sk + n*b_sn.
 // epilogue: 0 PassThrough (float->bhalf), 1 FastGelu<bhalf,float>,
 //           2 MultiplyAddFastGelu with d0[n], d1[n] bhalf (stride-0 rows),
-//           3 Add, 4 AddFastGelu, 5 Multiply, 6 MultiplyFastGelu with d0[n] bhalf (the multi-ABD instance family).
+//           3 Add, 4 AddFastGelu, 5 Multiply, 6 MultiplyFastGelu with d0[n] bhalf (the multi-ABD instance family),
+//           7 MultiplyAdd<bhalf> (bit patterns), 8 ConvertBF16RTN (float -> bhalf, nearest even).
 // b1 == nullptr: B = PassThrough(b0) (the "multiply" instances).
 void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1, uint16_t* e,
                         int M, int N, int K, int lda, int b_sk, int b_sn, int lde, int epilogue,
@@ -299,6 +308,8 @@ void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1,
                 ew::Multiply{}(y, tc(m, n), bhalf_t(d0[n]));
             else if(epilogue == 7)
                 ew::MultiplyAdd{}(y, tc(m, n), bhalf_t(d0[n]), bhalf_t(d1[n]));
+            else if(epilogue == 8)
+                ew::ConvertBF16RTN{}(y, tc(m, n));
             else
                 ew::MultiplyFastGelu{}(y, tc(m, n), bhalf_t(d0[n]));
             e[static_cast<size_t>(m) * lde + n] = y;

@@ -219,6 +219,22 @@ uint16_t wqo_multiply_add_bf16(float c, uint16_t d0, uint16_t d1)
     return (uint16_t)((uint32_t)wqo_f32_to_bf16(c) * (uint32_t)d0 + (uint32_t)d1);
 }
 
+/* type_convert.hpp:507-549  bf16_convert_rtn<bhalf_t, float>, reached through the functor ConvertBF16RTN
+ * (unary_element_wise_operation.hpp:236-251): round to nearest even on the upper 16 bits; Inf/NaN patterns are not
+ * incremented, and a NaN whose payload lies only in the lower 16 bits keeps a mantissa bit (0x10000 is or-ed in). */
+uint16_t wqo_bf16_convert_rtn(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const int finite = (~u & 0x7F800000u) != 0;
+    const int lownan = !finite && (u & 0xFFFFu);
+    if(finite)
+        u += 0x7FFFu + ((u >> 16) & 1u);
+    if(lownan)
+        u |= 0x10000u;
+    return (uint16_t)(u >> 16);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* input generators                                                                            */
 /* ------------------------------------------------------------------------------------------- */
@@ -509,6 +525,8 @@ void wqo_gemm_i8_bias_requant(const int8_t* a, const int8_t* b, const int32_t* b
  *            5 Multiply<bhalf>(float, bhalf)          binary_element_wise_operation.hpp:180-188
  *            6 MultiplyFastGelu<bhalf,float,bhalf>    binary_element_wise_operation.hpp:578-590
  *            7 MultiplyAdd<bhalf,float,bhalf,bhalf>   element_wise_operation.hpp:200-231 (d0, d1; bit-pattern arithmetic)
+ *            8 ConvertBF16RTN<bhalf,float>            unary_element_wise_operation.hpp:236-251 (float -> bhalf, nearest even;
+ *              the C element-wise operation of example/01_gemm/gemm_xdl_bf16_rtn.cpp:21)
  *   b1 == NULL: the "multiply" instances, B = PassThrough(b0) (int8 -> bhalf, exact), scale in the epilogue.
  * B element (k,n) at k*b_sk + n*b_sn.  D element (m,n) at m*ldd + n: the examples' d_m_n(m, n) over a row-major
  * descriptor with row stride StrideD (gemm_multi_ABD_xdl_bias_fastgelu_bf16_i8.cpp:86,140,263), 0 = one value per
@@ -552,6 +570,8 @@ static void bf16_i8_mn(void* p, int m, int n)
         y = wqo_f32_to_bf16(acc * wqo_bf16_to_f32(d0[n]));
     else if(x->epilogue == 7)
         y = wqo_multiply_add_bf16(acc, d0[n], d1[n]);
+    else if(x->epilogue == 8)
+        y = wqo_bf16_convert_rtn(acc);
     else
         y = wqo_f32_to_bf16(wqo_fastgelu(acc * wqo_bf16_to_f32(d0[n])));
     x->e[(size_t)m * x->lde + n] = y;

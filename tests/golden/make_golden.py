@@ -81,6 +81,18 @@ def scalars(ref) -> dict:
     b1 = bf16_bits_trunc(d1 - 0.5)
     out["mafg_d0"], out["mafg_d1"] = b0, b1
     out["mafg_bf16"] = np.array([ref.multiply_add_fastgelu_bf16(float(a), int(x), int(y)) for a, x, y in zip(c, b0, b1)], np.uint16)
+    # bf16_convert_rtn (type_convert.hpp:507-549) through the functor ConvertBF16RTN: random values, exact ties on both
+    # parities, carries into the exponent and into Inf, denormals, Inf and NaN patterns (payload in either half)
+    rb = np.concatenate([
+        (rng.uniform(-1, 1, 512) * rng.choice([1e-30, 1e-6, 1.0, 300.0, 3e38], 512)).astype(np.float32).view(np.uint32),
+        rng.integers(0, 2 ** 32, 512, dtype=np.uint64).astype(np.uint32),
+        np.array([0x3F808000, 0x3F818000, 0x3F808001, 0x3F807FFF, 0x3FFF8000, 0x3FFFFFFF, 0x7F7F8000, 0x7F7FFFFF,
+                  0x7F7F7FFF, 0x7F800000, 0xFF800000, 0x7FC00000, 0x7F800001, 0xFF80FFFF, 0x7FFFFFFF, 0x7F810000,
+                  0x00008000, 0x00007FFF, 0x00018000, 0x007F8000, 0x007FFFFF, 0x80000000, 0x00000000, 0x80008000,
+                  0xC02DF854, 0x477FE000], np.uint32),
+    ]).astype(np.uint32)
+    out["rtn_in_bits"] = rb
+    out["rtn_bf16"] = np.array([ref.bf16_convert_rtn(float(v)) if np.isfinite(v) or True else 0 for v in rb.view(np.float32)], np.uint16)
     # generators: first values of every (dtype, mode) the drivers use
     for dt in ("f16", "bf16", "i8", "f32"):
         for iv in (0, 1):
@@ -246,6 +258,16 @@ def gemm_cases(ref) -> dict:
     md1 = rng.integers(0, 65536, 512).astype(np.uint16)
     out["mad_c"], out["mad_d0"], out["mad_d1"] = mc, md0, md1
     out["mad_e"] = np.array([ref.multiply_add_bf16(float(c), int(a), int(b)) for c, a, b in zip(mc, md0, md1)], np.uint16)
+
+    # ---- ConvertBF16RTN as the C element-wise operation (example/01_gemm/gemm_xdl_bf16_rtn.cpp:21) on the bf16 x int8
+    # case above: Multiply on B (column-major B) and the unscaled row-major form, plus an integer-valued set whose
+    # accumulators hit exact ties (sums of odd multiples of 2^-8 scaled into [128, 256) have a set bit 16)
+    M, N, K = 48, 64, 128
+    out["bf16_e_col_ep8"] = ref.gemm_bf16_i8(out["bf16_a"], out["bf16_bcol"], out["bf16_s"], M, N, K, K, 1, K, N, 8, None, None)
+    out["bf16_mul_e_row_ep8"] = ref.gemm_bf16_i8(out["bf16_a"], brow, None, M, N, K, K, N, 1, N, 8, None, None)
+    a_tie = bf16_bits_trunc(rng.integers(-3, 4, (M, K)).astype(np.float32) * 0.5)
+    out["rtn_a_tie"] = a_tie
+    out["bf16_tie_e_row_ep8"] = ref.gemm_bf16_i8(a_tie, brow, None, M, N, K, K, N, 1, N, 8, None, None)
     return out
 
 

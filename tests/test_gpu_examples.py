@@ -49,6 +49,15 @@ def test_int8_bias_relu_quantization_example():
     assert "DeviceGemmBiasQuantization_gfx950" in r.stdout
 
 
+@pytest.mark.parametrize("init,shape", [(1, (512, 768, 1024)), (2, (512, 768, 1024)), (1, (100, 256, 256))])
+def test_bf16_i8_convert_rtn_example(init, shape):
+    """bf16 x int8 with ConvertBF16RTN as the C operation through DeviceGemmMultiABD_gfx950: bit-exact against the host
+    ReferenceGemm on the half-integer set (init 1), within one bf16 step (rtol 1e-2) on decimal values (init 2)."""
+    r = _run(os.path.join(EX, "example_gemm_bf16_i8_rtn_gfx950"), 1, init, 1, *shape)
+    assert r.returncode == 0 and "verification: PASS" in r.stdout
+    assert "Perf:" in r.stdout
+
+
 @pytest.mark.parametrize("name,op", [("gemm_xdl_quantization_int8", "DeviceGemmQuantization_gfx950"),
                                      ("gemm_xdl_bias_relu_quantization_int8", "DeviceGemmBiasQuantization_gfx950")])
 def test_reference_example14_sources_dropin(name, op):

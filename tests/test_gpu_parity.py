@@ -232,6 +232,51 @@ def test_bf16_multiply_add_bit_pattern_epilogue(golden_gemm, port):
     assert not capi.is_supported(p)
 
 
+def test_bf16_convert_rtn_epilogue(golden_gemm, port):
+    """ConvertBF16RTN (unary_element_wise_operation.hpp:236-251 -> type_convert.hpp:507-549) as the C operation: the
+    accumulator leaves rounded to nearest even.  Goldens from the reference functor bit for bit on the general kernel;
+    the tile, small-M and split-K paths on half-integer inputs, whose sums are exact in fp32 in any order and hit ties
+    (differences between the engine's two conversions are asserted to occur)."""
+    g = golden_gemm
+    M, N, K = 48, 64, 128
+    brow = np.ascontiguousarray(g["bf16_bcol"].T)
+    got = run_fpaintb(g["bf16_a"], g["bf16_bcol"], g["bf16_s"], M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
+                      epilogue=capi.EPI_CONVERT_BF16_RTN, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
+    np.testing.assert_array_equal(got, g["bf16_e_col_ep8"].reshape(M, N))
+    for a_key, e_key in (("bf16_a", "bf16_mul_e_row_ep8"), ("rtn_a_tie", "bf16_tie_e_row_ep8")):
+        got = run_fpaintb(g[a_key], brow, None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=capi.EPI_CONVERT_BF16_RTN,
+                          b_layout=capi.ROW_MAJOR, ldb=N, expect_kernel=GENERIC)
+        np.testing.assert_array_equal(got, g[e_key].reshape(M, N))
+    rng = np.random.default_rng(17)
+    differs = 0
+    for (M, N, K, flags, kern, kb) in ((256, 256, 192, capi.FLAG_TILE_128, MFMA, 1), (300, 256, 192, capi.FLAG_TILE_256, MFMA256, 1),
+                                       (256, 256, 256, capi.FLAG_TILE_256, MFMA256, 2), (24, 128, 256, 0, "wq_gemm_skinny", 1),
+                                       (8, 2048, 512, 0, "wq_gemm_skinny_ws", 1)):
+        q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        a = bf16_bits(np.round(rng.uniform(-4, 4, (M, K)) * 2) / 2)   # multiples of 1/2: exact sums, nine-bit results and more
+        got = run_fpaintb(a, q, None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=capi.EPI_CONVERT_BF16_RTN,
+                          flags=flags, k_batch=kb, expect_kernel=kern)
+        exp = port.gemm_bf16_i8(a, q, None, M, N, K, K, 1, K, N, 8).reshape(M, N)
+        np.testing.assert_array_equal(got, exp)
+        trunc = port.gemm_bf16_i8(a, q, None, M, N, K, K, 1, K, N, 0).reshape(M, N)
+        differs += int((exp != trunc).sum())
+    assert differs > 1000
+    # realistic values through the 256-tile kernel with Multiply on B: within one bf16 step of the checker's nearest-even
+    # result (fp32 summation order differs), never further
+    M, N, K = 256, 512, 1024
+    a = bf16_bits(rng.uniform(-1, 1, (M, K)))
+    s = bf16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    got = run_fpaintb(a, q, s, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, epilogue=capi.EPI_CONVERT_BF16_RTN,
+                      flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
+    exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 8).reshape(M, N)
+    check_err(bits_to_f32(got, capi.BF16), bits_to_f32(exp, capi.BF16), 1e-2, 1e-3)
+    # fp16 outputs have no such conversion
+    p = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, 256, 256, 256, a_dtype=capi.F16, b_dtype=capi.I8,
+                             epilogue=capi.EPI_CONVERT_BF16_RTN)
+    assert not capi.is_supported(p)
+
+
 @pytest.mark.parametrize("a_dtype", [capi.F16, capi.BF16])
 def test_row_major_b_via_transpose(port, a_dtype):
     """8-bit weights stored (K, N) row-major: with a workspace the launch transposes them and runs the matrix-core

@@ -16,6 +16,11 @@ def test_scalar_functions_random(port, ref):
         for s in rng.integers(0, 0x7C00, 24):
             assert port.dequant_f16(q, int(s)) == ref.dequant_f16(q, int(s))
             assert port.multiply_bf16(q, int(s)) == ref.multiply_bf16(q, int(s))
+    # bf16_convert_rtn on arbitrary bit patterns (NaN and Inf patterns included)
+    for u in rng.integers(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.uint32):
+        f = float(np.uint32(u).view(np.float32))
+        if f == f:  # a Python float cannot carry a NaN payload through ctypes unchanged
+            assert port.bf16_convert_rtn(f) == ref.bf16_convert_rtn(f)
     for x in rng.integers(-200000, 200000, 3000):
         assert port.act_mul_clamp(0.03, int(x)) == ref.act_mul_clamp(0.03, int(x))
         assert port.act_mul_clamp_from_float(0.03, float(x)) == ref.act_mul_clamp_from_float(0.03, float(x))
@@ -47,7 +52,7 @@ def test_bf16_and_f8_random(port, ref):
     b = rng.integers(-128, 128, (N, K)).astype(np.int8)
     d0 = (rng.uniform(0.5, 1.5, N).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
     d1 = (rng.uniform(-0.5, 0.5, N).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
-    for ep in (0, 1, 2, 3, 4, 5, 6):
+    for ep in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         np.testing.assert_array_equal(port.gemm_bf16_i8(a, b, s, M, N, K, K, 1, K, N, ep, d0, d1),
                                       ref.gemm_bf16_i8(a, b, s, M, N, K, K, 1, K, N, ep, d0, d1))
         np.testing.assert_array_equal(port.gemm_bf16_i8(a, b, None, M, N, K, K, 1, K, N, ep, d0, d1),

@@ -13,10 +13,14 @@ M = N = 4096
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 F8 = len(sys.argv) > 3 and sys.argv[3] == "f8"
+ZERO = len(sys.argv) > 4 and sys.argv[4] == "zero"  # all-zero operands: the same instruction stream at minimal switching power
 dev = torch.device("cuda", 0)
 a = (torch.rand((M, K), device=dev) * 2 - 1).half()
 q = torch.randint(-8, 8, (N, K), device=dev, dtype=torch.int8)
 s = (torch.rand((N,), device=dev) * 0.05 + 0.004).half()
+if ZERO:
+    a.zero_()
+    q.zero_()
 b = torch.empty((N, K // 2), dtype=torch.uint8, device=dev)
 sp = torch.cuda.current_stream().cuda_stream
 capi.pack_int4(q.data_ptr(), K, K, N, b.data_ptr(), K // 2, sp)
