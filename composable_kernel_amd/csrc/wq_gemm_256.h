@@ -223,6 +223,28 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
         b_src[i]        = (const uint8_t*)p.b + (size_t)(n0 + col) * p.ldb_bytes +
                    (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + chunk * 16;
     }
+    // Pre-shuffled packed int4 (p.b_preshuf): the 32 columns x 64 k a wave moves per K tile are one contiguous KiB of
+    // global memory, already in the order of the LDS image (unit (column 16 t + r, k half h) at 16-byte slot
+    // 32 t + 16 h + r), so lane l copies slot l and consecutive K tiles are 1024 bytes apart.
+    size_t b_tile_stride = T::B_ROW_BYTES;
+    // per-lane byte offset, inside the B image of a K tile, of this lane's 4 bytes of k-step s of its column of
+    // column block nt = 0 (further column blocks: + 512 nt in both layouts)
+    int raw_off[2] = {0, 0};
+    if constexpr(BKIND == B_I4P)
+    {
+#pragma unroll
+        for(int s = 0; s < 2; ++s)
+            raw_off[s] = (col_w + fr) * 32 + ((s ^ ((fr >> 2) & 1)) << 4) + fq * 4; // (col >> 2) & 1 == (fr >> 2) & 1
+        if(p.b_preshuf)
+        {
+            b_src[0] = (const uint8_t*)p.b + (size_t)((n0 >> 5) + wave) * ((size_t)p.ldb_bytes * 32) +
+                       (size_t)(kz_begin >> 6) * 1024 + lane * 16;
+            b_tile_stride = 1024;
+#pragma unroll
+            for(int s = 0; s < 2; ++s)
+                raw_off[s] = (col_w >> 5) * 1024 + (s * 16 + fr) * 16 + fq * 4;
+        }
+    }
 
     auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         uint8_t* sa = lds + buf * T::STAGE;
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
             glds16(a_src[i] + (size_t)kt * T::A_ROW_BYTES, sa + (wave * T::A_DMA + i) * 1024);
 #pragma unroll
         for(int i = 0; i < T::B_DMA; ++i)
-            glds16(b_src[i] + (size_t)kt * T::B_ROW_BYTES, sb + (wave * T::B_DMA + i) * 1024);
+            glds16(b_src[i] + (size_t)kt * b_tile_stride, sb + (wave * T::B_DMA + i) * 1024);
     };
 
     f4_t acc[NT][MT];
@@ -260,9 +282,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
 #pragma unroll
         for(int nt = 0; nt < NT; ++nt)
         {
-            const int col = col_w + nt * 16 + fr;
+            [[maybe_unused]] const int col = col_w + nt * 16 + fr;
             if constexpr(BKIND == B_I4P)
-                raw4[nt] = *(const uint32_t*)(sb + col * 32 + ((s ^ ((col >> 2) & 1)) << 4) + fq * 4);
+                raw4[nt] = *(const uint32_t*)(sb + raw_off[s] + nt * 512);
             else
                 raw8[nt] = *(const u2_t*)(sb + col * 64 + (((2 * s + (fq >> 1)) ^ ((col >> 2) & 3)) << 4) +
                                           (fq & 1) * 8);
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                     if(i < T::A_DMA)
                         glds16(a_src[i] + (size_t)kt * T::A_ROW_BYTES, sa + (wave * T::A_DMA + i) * 1024);
                     else
-                        glds16(b_src[i - T::A_DMA] + (size_t)kt * T::B_ROW_BYTES,
+                        glds16(b_src[i - T::A_DMA] + (size_t)kt * b_tile_stride,
                                sb + (wave * T::B_DMA + (i - T::A_DMA)) * 1024);
                 }
             };
@@ -364,9 +386,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
 #pragma unroll
                 for(int nt = 0; nt < NT; ++nt)
                 {
-                    const int col = col_w + nt * 16 + fr;
+                    [[maybe_unused]] const int col = col_w + nt * 16 + fr;
                     if constexpr(BKIND == B_I4P)
-                        raw4[nt] = *(const uint32_t*)(sb + col * 32 + ((s ^ ((col >> 2) & 1)) << 4) + fq * 4);
+                        raw4[nt] = *(const uint32_t*)(sb + raw_off[s] + nt * 512);
                     else
                         raw8[nt] = *(const u2_t*)(sb + col * 64 + (((2 * s + (fq >> 1)) ^ ((col >> 2) & 3)) << 4) +
                                                   (fq & 1) * 8);

@@ -83,11 +83,17 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
         a_run[i] = (uint32_t)(m0 + (wave * T::A_DMA + i) * 8) * (uint32_t)p.lda + kz_begin;
     const uint32_t a_lane = (uint32_t)(lane >> 3) * p.lda + (((lane & 7) ^ f8_a_swz(lane >> 3)) << 4);
     // Weights: lane (fr, fq) owns bytes [16 fq, 16 fq + 16) of the 64-byte K-tile row of columns col_w + 16 nt + fr
+    // Pre-shuffled weights (p.b_preshuf; blocks of 32 columns x 64 k = 1 KiB, unit (column 16 t + r, k half h) at slot
+    // 32 t + 16 h + r, blocks of one column block consecutive along K): the lane's 32 k of K tile `tile` are k half
+    // fq % 2 of block 2 tile + fq / 2, i.e. a wave-wide load reads four runs of 256 bytes.
     uint32_t b_voff[NT];
 #pragma unroll
     for(int nt = 0; nt < NT; ++nt)
-        b_voff[nt] = (uint32_t)(n0 + col_w + nt * 16 + fr) * (uint32_t)p.ldb_bytes + fq * 16;
-    const uint32_t b_base = kz_begin / 2;
+        b_voff[nt] = p.b_preshuf ? (uint32_t)((n0 + col_w) >> 5) * ((uint32_t)p.ldb_bytes * 32) + (uint32_t)(fq >> 1) * 1024 +
+                                       (uint32_t)((nt * 32 + (fq & 1) * 16 + fr) * 16)
+                                 : (uint32_t)(n0 + col_w + nt * 16 + fr) * (uint32_t)p.ldb_bytes + fq * 16;
+    const uint32_t b_base      = p.b_preshuf ? (uint32_t)(kz_begin >> 6) * 1024 : kz_begin / 2;
+    const uint32_t b_tile_step = p.b_preshuf ? 2048 : T::BK / 2;
 
     auto dma_a = [&](const __amdgpu_buffer_rsrc_t& rsrc, int slot, int i) __attribute__((always_inline)) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + slot * T::A_TILE + (wave * T::A_DMA + i) * 1024),
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
     };
     // weights of K tile `tile` (scalar byte offset = the loads' soffset)
     auto load_b = [&](const __amdgpu_buffer_rsrc_t& rsrc, u4_t(&dst)[NT], int tile) __attribute__((always_inline)) {
-        const uint32_t soff = __builtin_amdgcn_readfirstlane(b_base + (uint32_t)tile * (T::BK / 2));
+        const uint32_t soff = __builtin_amdgcn_readfirstlane(b_base + (uint32_t)tile * b_tile_step);
 #pragma unroll
         for(int nt = 0; nt < NT; ++nt)
             dst[nt] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b_voff[nt], soff, 0));

@@ -38,7 +38,16 @@ struct GemmParams
     EpilogueArgs epi;
     int scale_group_k; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
     int ld_scale;
+    int b_preshuf;     // packed int4 weights in the pre-shuffled order (blocks of 32 columns x 64 k = 1 KiB; column-block
+                       // pitch = 32 * ldb_bytes): 256-tile kernels only
 };
+
+// Byte offset of the 16-byte unit (32 consecutive k from 32 * k32 of column n) inside pre-shuffled int4 weights.
+__host__ __device__ __forceinline__ size_t preshuf_unit_offset(int n, int k32, int ldb_bytes)
+{
+    return (size_t)(n >> 5) * ((size_t)ldb_bytes * 32) + (size_t)(k32 >> 1) * 1024 +
+           (size_t)((((n >> 4) & 1) * 32 + (k32 & 1) * 16 + (n & 15)) * 16);
+}
 
 // XCD-aware block remap: blocks b and b + 8 share an XCD (and its L2) under round-robin
 // dispatch, so give each of the 8 groups a contiguous run of tile ids.  Bijective for any grid.
@@ -888,9 +897,11 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
         if(p.scale_group_k > 0)
             sbits = ((const uint16_t*)p.scale)[(size_t)(k / p.scale_group_k) * p.ld_scale + n];
         int q;
-        if(p.b_dtype == 6 /*WQ_I4_PACKED*/)
+        if(p.b_dtype == 6 /*WQ_I4_PACKED*/ || p.b_dtype == 9 /*WQ_I4_PRESHUFFLED*/)
         {
-            const uint32_t w = *(const uint32_t*)((const uint8_t*)p.b + (size_t)n * p.b_sn + (k >> 3) * 4);
+            const uint8_t* unit = p.b_dtype == 6 ? (const uint8_t*)p.b + (size_t)n * p.b_sn + (k >> 5) * 16
+                                                 : (const uint8_t*)p.b + preshuf_unit_offset(n, k >> 5, p.b_sn);
+            const uint32_t w = *(const uint32_t*)(unit + ((k >> 3) & 3) * 4);
             const int j      = k & 7;
             const int pos    = (j & 1) ? 4 + (j >> 1) : (j >> 1);
             q                = (int)((w >> (4 * pos)) & 0xFu) - 8;
@@ -992,6 +1003,27 @@ __global__ __launch_bounds__(256) void wq_pack_int4(const int8_t* __restrict__ q
             w |= (uint32_t)((src[k] + 8) & 0xF) << (4 * pos);
         }
         *(uint32_t*)(out + (size_t)n * ld_bytes + 4 * g) = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// packed int4 -> pre-shuffled int4: one thread per 16-byte unit (32 consecutive k of one column).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wq_preshuffle_int4(const uint8_t* __restrict__ packed, int ld_bytes, int K, int N,
+                                                          uint8_t* __restrict__ out, int ldb_bytes_out)
+{
+    const int units  = K >> 5;
+    const long total = (long)N * units;
+    for(long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    {
+        // consecutive threads write consecutive units of the destination
+        const long blk = i >> 6;
+        const int u    = (int)(i & 63);
+        const int kbs  = K >> 6; // 64-k blocks per column block
+        const int cb = (int)(blk / kbs), kb = (int)(blk % kbs);
+        const int n = cb * 32 + (u >> 5) * 16 + (u & 15), k32 = kb * 2 + ((u >> 4) & 1);
+        const u4_t v = *(const u4_t*)(packed + (size_t)n * ld_bytes + (size_t)k32 * 16);
+        *(u4_t*)(out + preshuf_unit_offset(n, k32, ldb_bytes_out)) = v;
     }
 }
 

@@ -85,6 +85,7 @@ struct Plan
 };
 
 bool is16(int dt) { return dt == WQ_F16 || dt == WQ_BF16; }
+bool is_i4(int dt) { return dt == WQ_I4_PACKED || dt == WQ_I4_PRESHUFFLED; } // two nibbles per byte, either unit order
 
 // Epilogues of the floating-point family and the D vectors each one reads.
 int check_fp_epilogue(const wqgemm_problem* p)
@@ -143,7 +144,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // they are addressed as given.  The output stride must keep rows apart.
     if(p->lda <= 0 || p->ldb <= 0)
         return fail(WQ_ERR_INVALID, "lda and ldb must be positive");
-    if(p->b_dtype == WQ_I4_PACKED && p->ldb < p->K)
+    if(is_i4(p->b_dtype) && p->ldb < p->K)
         return fail(WQ_ERR_INVALID, "ldb too small for packed int4 columns");
     if(p->ldc < p->N)
         return fail(WQ_ERR_INVALID, "ldc too small");
@@ -198,13 +199,16 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // ---- fpAintB family ------------------------------------------------------------------------
     if(p->a_dtype != WQ_F16 && p->a_dtype != WQ_BF16 && p->a_dtype != WQ_F8_FNUZ && p->a_dtype != WQ_F8_E4M3FN)
         return fail(WQ_ERR_UNSUPPORTED, "unsupported A dtype %d", p->a_dtype);
-    if(p->b_dtype != WQ_I4_PACKED && p->b_dtype != WQ_U8_OFFSET && p->b_dtype != WQ_I8)
+    if(!is_i4(p->b_dtype) && p->b_dtype != WQ_U8_OFFSET && p->b_dtype != WQ_I8)
         return fail(WQ_ERR_UNSUPPORTED, "unsupported B dtype %d", p->b_dtype);
-    if(p->b_dtype == WQ_I4_PACKED && (p->b_layout != WQ_COL_MAJOR || p->K % 8 != 0 || p->ldb % 8 != 0))
+    if(is_i4(p->b_dtype) && (p->b_layout != WQ_COL_MAJOR || p->K % 8 != 0 || p->ldb % 8 != 0))
         return fail(WQ_ERR_UNSUPPORTED,
                     "packed int4 B must be column-major (K contiguous) with K and ldb multiples of 8");
-    if(p->b_dtype == WQ_I4_PACKED && (plan.k_begin % 8 != 0 || plan.k_per_z % 8 != 0))
+    if(is_i4(p->b_dtype) && (plan.k_begin % 8 != 0 || plan.k_per_z % 8 != 0))
         return fail(WQ_ERR_UNSUPPORTED, "packed int4 K slices must start on multiples of 8");
+    const bool preshuf = p->b_dtype == WQ_I4_PRESHUFFLED;
+    if(preshuf && (p->N % 32 != 0 || p->K % 64 != 0 || p->ldb % 64 != 0 || plan.k_begin % 64 != 0 || plan.k_per_z % 64 != 0))
+        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled int4 B: N must be a multiple of 32; K, ldb and K slices multiples of 64");
     if(is16(p->a_dtype))
     {
         if(p->scale && p->scale_dtype != p->a_dtype)
@@ -236,11 +240,11 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return rc;
 
     plan.ak = p->a_dtype == WQ_BF16 ? wq::A_BF16 : wq::A_F16;
-    plan.bk = p->b_dtype == WQ_I4_PACKED ? wq::B_I4P : (p->b_dtype == WQ_U8_OFFSET ? wq::B_U8O : wq::B_I8);
+    plan.bk = is_i4(p->b_dtype) ? wq::B_I4P : (p->b_dtype == WQ_U8_OFFSET ? wq::B_U8O : wq::B_I8);
 
     // The tiled MFMA kernel needs whole tiles along K, N % 4 == 0 (its last row and column tiles may be partial),
     // K-contiguous operands and 16-byte aligned rows; everything else goes to the generic kernel.
-    const int b_row_align = p->b_dtype == WQ_I4_PACKED ? 32 : 16; // ldb elements per 16 bytes
+    const int b_row_align = is_i4(p->b_dtype) ? 32 : 16; // ldb elements per 16 bytes
     const bool tiled = is16(p->a_dtype) && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
                        p->N % 4 == 0 && plan.k_begin % 64 == 0 &&
                        plan.k_per_z % 64 == 0 && (plan.k_end - plan.k_begin) % 64 == 0 &&
@@ -251,9 +255,9 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     plan.route = tiled && !(p->flags & WQ_FLAG_GENERIC) ? ROUTE_MFMA128 : ROUTE_GENERIC;
     // Small M (decode-like shapes): HBM-bound, one pass over the weights; its own kernel with split-K for occupancy.
     {
-        const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64; // k per super-step of wq_gemm_skinny
+        const int ks        = is_i4(p->b_dtype) ? 128 : 64; // k per super-step of wq_gemm_skinny
         const int klen_all  = plan.k_end - plan.k_begin;
-        const bool eligible = is16(p->a_dtype) && !grouped && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
+        const bool eligible = is16(p->a_dtype) && !grouped && !preshuf && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                               p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 &&
                               klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
                               p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 &&
@@ -281,7 +285,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                 // in slices of whole 4-super-step groups when K allows (the kernel then keeps 4 loads in flight).
                 const int gran       = klen_all % (4 * ks) == 0 ? 4 * ks : ks;
                 const int wgs        = p->N / 64;
-                const long wbytes_k  = p->b_dtype == WQ_I4_PACKED ? klen_all / 2 : klen_all; // weight bytes per column
+                const long wbytes_k  = is_i4(p->b_dtype) ? klen_all / 2 : klen_all; // weight bytes per column
                 const int kb_occ     = (1024 + wgs - 1) / wgs;
                 const long kb_bytes  = wbytes_k / (16L * p->M);
                 kb                   = kb_occ;
@@ -308,7 +312,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // Split-K by the caller (k_batch > 1) combines with it: the slabs come first in the workspace, the copy after them.
     if(plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) && is16(p->a_dtype) && !slice &&
        plan.k_per_z % 64 == 0 && (!grouped || p->scale_group_k % 64 == 0) &&
-       p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_ROW_MAJOR && p->b_dtype != WQ_I4_PACKED &&
+       p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_ROW_MAJOR && !is_i4(p->b_dtype) &&
        p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % 16 == 0 && p->ldc % 4 == 0 &&
        (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0 && (uintptr_t)p->scale % 2 == 0)
     {
@@ -319,7 +323,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // FNUZ bytes qualify only when the caller excludes the three encodings E4M3FN cannot express.
     const bool is_f8 = p->a_dtype == WQ_F8_FNUZ || p->a_dtype == WQ_F8_E4M3FN;
     if(is_f8 && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
-       p->b_dtype == WQ_I4_PACKED && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->M > 64 && p->N % 256 == 0 &&
+       is_i4(p->b_dtype) && !(preshuf && (p->flags & WQ_FLAG_PINGPONG)) && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->M > 64 && p->N % 256 == 0 &&
        plan.k_begin % 128 == 0 && plan.k_per_z % 128 == 0 && (plan.k_end - plan.k_begin) % 128 == 0 &&
        p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
        (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
@@ -345,7 +349,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
         const long wgs = (long)((p->M + 255) / 256) * (p->N / 256) * plan.k_batch;
-        if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256))
+        // (pre-shuffled weights exist for this kernel family only: short grids run it too)
+        if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256) || preshuf)
             plan.route = ROUTE_MFMA256;
     }
     // Few tiles (a short M against a narrow N) leave most CUs idle: split K across blockIdx.z when the caller has not,
@@ -372,6 +377,14 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
             }
         }
     }
+    // Pre-shuffled weights are laid out for the 256-tile kernels (and readable by the general kernel when it is asked
+    // for by name); there is no slow path to fall onto silently.
+    if(preshuf && plan.route != ROUTE_MFMA256 && plan.route != ROUTE_F8_MFMA256 && !(p->flags & WQ_FLAG_GENERIC))
+        return fail(WQ_ERR_UNSUPPORTED,
+                    "pre-shuffled int4 B runs on the 256-tile kernels only: N %% 256 == 0, K in whole 64-k tiles (128 for fp8 "
+                    "activations), K-contiguous 16-byte aligned operands, default wave grid");
+    if(preshuf && (p->flags & (WQ_FLAG_MFMA_32X32 | WQ_FLAG_TILE_128)))
+        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled int4 B: no 128-tile or 32x32-MFMA kernel reads this layout");
     if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)
         return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs N to be a multiple of 256 and tile-aligned operands");
     if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_MFMA128)
@@ -444,7 +457,8 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.N         = p->N;
         gp.K         = p->K;
         if(!plan.via_colb)
-            gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb;
+            gp.ldb_bytes = is_i4(p->b_dtype) ? p->ldb / 2 : p->ldb;
+        gp.b_preshuf = p->b_dtype == WQ_I4_PRESHUFFLED ? 1 : 0;
         gp.ldc       = ld_out;
         gp.k_begin   = plan.k_begin;
         gp.k_end     = plan.k_end;
@@ -462,7 +476,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
             // Tiles are dealt to the 8 XCDs in contiguous runs of nwg/8 (xcd_remap); inside a run the
             // walk covers group_m tile rows x (run / group_m) tile columns.  Pick the group that
             // minimises the bytes one XCD pulls through its L2: g rows of A plus run/g columns of B.
-            const double a_bytes = (plan.route == ROUTE_F8_MFMA256 ? 1.0 : 2.0) * tile, b_bytes = (p->b_dtype == WQ_I4_PACKED ? 0.5 : 1.0) * tile;
+            const double a_bytes = (plan.route == ROUTE_F8_MFMA256 ? 1.0 : 2.0) * tile, b_bytes = (is_i4(p->b_dtype) ? 0.5 : 1.0) * tile;
             const int run        = (gp.tiles_m * gp.tiles_n + 7) / 8;
             int best = 1;
             double best_cost = 1e30;
@@ -524,12 +538,12 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         wq::GemmParams gp{};
         gp.a = p->a, gp.b = p->b, gp.scale = p->scale, gp.c = out;
         gp.M = p->M, gp.N = p->N, gp.K = p->K;
-        gp.lda = p->lda, gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb, gp.ldc = ld_out;
+        gp.lda = p->lda, gp.ldb_bytes = is_i4(p->b_dtype) ? p->ldb / 2 : p->ldb, gp.ldc = ld_out;
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end, gp.k_per_z = plan.k_per_z;
         gp.partial = plan.partial ? 1 : 0;
         gp.epi     = epilogue_of(p);
         const int nmb       = p->M <= 16 ? 1 : (p->M <= 32 ? 2 : 4);
-        const int ks        = p->b_dtype == WQ_I4_PACKED ? 128 : 64;
+        const int ks        = is_i4(p->b_dtype) ? 128 : 64;
         // 4 loads in flight when every slice is a whole number of 4-super-step groups
         const int klen      = plan.k_end - plan.k_begin;
         const bool by4      = plan.k_per_z % (4 * ks) == 0 && klen % (4 * ks) == 0;
@@ -543,10 +557,10 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         wq::GemmParams gp{};
         gp.a = p->a, gp.b = p->b, gp.scale = p->scale, gp.c = p->c;
         gp.M = p->M, gp.N = p->N, gp.K = p->K;
-        gp.lda = p->lda, gp.ldb_bytes = p->b_dtype == WQ_I4_PACKED ? p->ldb / 2 : p->ldb, gp.ldc = p->ldc;
+        gp.lda = p->lda, gp.ldb_bytes = is_i4(p->b_dtype) ? p->ldb / 2 : p->ldb, gp.ldc = p->ldc;
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end;
         gp.epi     = epilogue_of(p);
-        const int ks = p->b_dtype == WQ_I4_PACKED ? 128 : 64, klen = plan.k_end - plan.k_begin;
+        const int ks = is_i4(p->b_dtype) ? 128 : 64, klen = plan.k_end - plan.k_begin;
         // loads in flight = super-steps per unit of K dealt to a wave: as many as leave every wave at least one unit
         const int steps   = klen / ks;
         const int p_loads = steps % 4 == 0 && steps / 4 >= 4 ? 4 : (steps % 2 == 0 && steps / 2 >= 4 ? 2 : 1);
@@ -608,7 +622,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.K     = p->K;
         gp.a_sm  = p->a_layout == WQ_ROW_MAJOR ? p->lda : 1;
         gp.a_sk  = p->a_layout == WQ_ROW_MAJOR ? 1 : p->lda;
-        if(p->b_dtype == WQ_I4_PACKED)
+        if(is_i4(p->b_dtype))
         {
             gp.b_sk = 0;
             gp.b_sn = p->ldb / 2;
@@ -659,6 +673,7 @@ const char* dt_name(int dt)
     case WQ_I8: return "I8";
     case WQ_U8_OFFSET: return "U8";
     case WQ_I4_PACKED: return "I4";
+    case WQ_I4_PRESHUFFLED: return "I4_PRESHUFFLED";
     case WQ_I32: return "I32";
     default: return "?";
     }
@@ -863,7 +878,7 @@ static size_t b_span_bytes(const wqgemm_problem* p)
 {
     const size_t rows = p->b_layout == WQ_COL_MAJOR ? p->N : p->K, cols = p->b_layout == WQ_COL_MAJOR ? p->K : p->N;
     const size_t elems = (rows - 1) * (size_t)p->ldb + cols;
-    return p->b_dtype == WQ_I4_PACKED ? (elems + 1) / 2 : elems;
+    return is_i4(p->b_dtype) ? (elems + 1) / 2 : elems;
 }
 
 int wqgemm_run_timed_rotating(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters, int nrepeat,
@@ -1021,6 +1036,37 @@ int wqgemm_pack_int4(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t
     hipLaunchKernelGGL(wq::wq_pack_int4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q, ldq, K,
                        N, out, ld_bytes);
     WQ_HIP(hipGetLastError());
+    return WQ_OK;
+}
+
+int wqgemm_preshuffle_int4(const uint8_t* packed, int32_t ld_bytes, int32_t K, int32_t N, uint8_t* out, int32_t ldk,
+                           void* stream)
+{
+    if(!packed || !out)
+        return fail(WQ_ERR_INVALID, "null pointer");
+    if(K <= 0 || N <= 0 || K % 64 != 0 || N % 32 != 0 || ld_bytes < K / 2 || ld_bytes % 16 != 0 || ldk < K || ldk % 64 != 0 ||
+       (uintptr_t)packed % 16 != 0 || (uintptr_t)out % 16 != 0)
+        return fail(WQ_ERR_INVALID, "preshuffle_int4: need K %% 64 == 0, N %% 32 == 0, 16-byte aligned columns (ld_bytes %% 16 == 0, "
+                                    "ld_bytes >= K/2), ldk >= K, ldk %% 64 == 0");
+    const long work = (long)N * (K / 32);
+    int blocks      = (int)((work + 255) / 256);
+    if(blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(wq::wq_preshuffle_int4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, ld_bytes, K, N, out,
+                       ldk / 2);
+    WQ_HIP(hipGetLastError());
+    return WQ_OK;
+}
+
+int wqgemm_preshuffle_int4_host(const uint8_t* packed, int32_t ld_bytes, int32_t K, int32_t N, uint8_t* out, int32_t ldk)
+{
+    if(!packed || !out)
+        return fail(WQ_ERR_INVALID, "null pointer");
+    if(K <= 0 || N <= 0 || K % 64 != 0 || N % 32 != 0 || ld_bytes < K / 2 || ldk < K || ldk % 64 != 0)
+        return fail(WQ_ERR_INVALID, "preshuffle_int4_host: need K %% 64 == 0, N %% 32 == 0, ld_bytes >= K/2, ldk >= K, ldk %% 64 == 0");
+    for(int n = 0; n < N; ++n)
+        for(int k32 = 0; k32 < K / 32; ++k32)
+            memcpy(out + wq::preshuf_unit_offset(n, k32, ldk / 2), packed + (size_t)n * ld_bytes + (size_t)k32 * 16, 16);
     return WQ_OK;
 }
 

@@ -18,8 +18,11 @@ _EPILOGUES = {"none": capi.EPI_PASSTHROUGH, "fastgelu": capi.EPI_FASTGELU, "add"
 
 @torch.library.custom_op("wqgemm::fpaintb_linear", mutates_args=())
 def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, bits: int, epilogue: str,
-                   bias: torch.Tensor | None) -> torch.Tensor:
+                   bias: torch.Tensor | None, layout: str = "packed") -> torch.Tensor:
     """y[m, n] = epilogue( sum_k x[m, k] * dequant(weight[n, k], scale[n]) [, bias[n]] ).
+
+    layout = "preshuffled" (bits = 4): the weight bytes are in the order of wqgemm_preshuffle_int4; runs on the 256-tile
+    kernels only (N a multiple of 256, K of 64) and raises where they cannot take the problem.
 
     x (M, K) fp16 / bf16, row-major; weight uint8 (N, K/2) packed int4 (bits = 4) or int8 (N, K) (bits = 8);
     scale and bias (N,) of x's dtype; epilogue in {"none", "fastgelu", "add", "add_fastgelu"}.
@@ -34,6 +37,8 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
         raise ValueError("bias goes with the add / add_fastgelu epilogues only")
     if bits not in (4, 8):
         raise ValueError(f"bits must be 4 (packed int4) or 8 (int8), got {bits}")
+    if layout not in ("packed", "preshuffled") or (layout == "preshuffled" and bits != 4):
+        raise ValueError(f"layout must be 'packed', or 'preshuffled' with bits = 4, got {layout!r} with bits = {bits}")
     if x.dim() != 2 or scale.dim() not in (1, 2):
         raise ValueError("x must be (M, K) and scale (N,) or (groups, N)")
     M, K = x.shape
@@ -64,9 +69,12 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     # any M runs as it is: small-M kernel up to 64 rows, the tile kernels with a partial last row tile beyond
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     p = capi.fpAintB_problem(x.data_ptr(), weight.data_ptr(), scale.data_ptr(), y.data_ptr(), M, N, K,
-                             a_dtype=_DT[x.dtype], b_dtype=capi.I4_PACKED if bits == 4 else capi.I8,
+                             a_dtype=_DT[x.dtype],
+                             b_dtype=(capi.I4_PRESHUFFLED if layout == "preshuffled" else capi.I4_PACKED) if bits == 4 else capi.I8,
                              epilogue=_EPILOGUES[epilogue], d0=bias.data_ptr() if bias is not None else None,
                              scale_group_k=group_k)
+    if not capi.is_supported(p):
+        raise RuntimeError("wqgemm::fpaintb_linear: " + capi.lib.wqgemm_last_error().decode())
     nbytes = capi.workspace_bytes(p)  # optional scratch (the planner's split-K partials)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
@@ -75,7 +83,7 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
 
 
 @fpaintb_linear.register_fake
-def _(x, weight, scale, bits, epilogue, bias):
+def _(x, weight, scale, bits, epilogue, bias, layout="packed"):
     return x.new_empty((x.shape[0], scale.shape[-1]))
 
 
@@ -85,7 +93,7 @@ class WqLinear(torch.nn.Module):
     def __init__(self, pw: PackedWeights, bias: torch.Tensor | None = None, epilogue: str = "none", device="cuda"):
         super().__init__()
         dt = torch.float16 if pw.scale_dtype == "f16" else torch.bfloat16
-        self.bits, self.in_features, self.out_features = pw.bits, pw.K, pw.N
+        self.bits, self.in_features, self.out_features, self.layout = pw.bits, pw.K, pw.N, pw.layout
         self.register_buffer("weight", torch.from_numpy(pw.weight.copy()).to(device))
         self.register_buffer("scale", torch.from_numpy(pw.scale.view("int16").copy()).view(dt).to(device))
         self.register_buffer("bias", None if bias is None else bias.to(device=device, dtype=dt))
@@ -93,5 +101,6 @@ class WqLinear(torch.nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lead = x.shape[:-1]
-        y = fpaintb_linear(x.reshape(-1, self.in_features), self.weight, self.scale, self.bits, self.epilogue, self.bias)
+        y = fpaintb_linear(x.reshape(-1, self.in_features), self.weight, self.scale, self.bits, self.epilogue, self.bias,
+                           self.layout)
         return y.reshape(*lead, self.out_features)

@@ -12,11 +12,18 @@ array, one row of N scales per group: the (K, N) scale tensor of the reference's
 (library/include/ck/library/reference_tensor_operation/cpu/reference_fpAintB_gemm.hpp:62-127) with repeated rows
 collapsed, in the (K / block, N) shape of example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:126-152.
 
+Packed int4 weights can additionally be stored pre-shuffled (``preshuffle``; ``WQ_I4_PRESHUFFLED``, the layout documented
+at ``wqgemm_preshuffle_int4``): the same bytes with their 16-byte units (32 consecutive k of one column) in the order the
+256-tile kernels fetch them, so that every wave-wide weight fetch is one contiguous kilobyte.  Such weights run on those
+kernels only (N a multiple of 256, K of 64).
+
 Container (``save_packed`` / ``load_packed``): a NumPy ``.npz`` archive with the arrays ``weight`` (uint8 or int8,
-shape (N, K/2) or (N, K)), ``scale`` (uint16 bit patterns of fp16 / bf16, shape (N,), or (K / group_k, N) for
-group-wise scales) and the 0-d entries ``format`` ("wqgemm-weights-2"; "wqgemm-weights-1" files, which have no
-``group_k``, still load), ``bits`` (4 or 8), ``scale_dtype`` ("f16" or "bf16"), ``N``, ``K`` and ``group_k`` (0 = one scale
-per channel).  Loaded with ``allow_pickle=False``.
+shape (N, K/2) or (N, K); for the pre-shuffled layout the N * K / 2 bytes keep the (N, K/2) shape although rows no longer
+are columns), ``scale`` (uint16 bit patterns of fp16 / bf16, shape (N,), or (K / group_k, N) for
+group-wise scales) and the 0-d entries ``format`` ("wqgemm-weights-3"; "wqgemm-weights-2" files, which have no ``layout``,
+and "wqgemm-weights-1" files, which have no ``group_k`` either, still load), ``bits`` (4 or 8), ``scale_dtype`` ("f16" or
+"bf16"), ``N``, ``K``, ``group_k`` (0 = one scale per channel) and ``layout`` ("packed" or "preshuffled").  Loaded with
+``allow_pickle=False``.
 """
 from __future__ import annotations
 
@@ -26,8 +33,9 @@ import numpy as np
 
 from . import capi
 
-FORMAT = "wqgemm-weights-2"
-FORMATS_READ = ("wqgemm-weights-1", FORMAT)
+FORMAT = "wqgemm-weights-3"
+FORMATS_READ = ("wqgemm-weights-1", "wqgemm-weights-2", FORMAT)
+LAYOUTS = ("packed", "preshuffled")
 
 
 @dataclass
@@ -39,10 +47,13 @@ class PackedWeights:
     N: int
     K: int
     group_k: int = 0        # 0: one scale per output channel; g: one per channel and per g consecutive k
+    layout: str = "packed"  # "preshuffled": 4-bit weights in the order of wqgemm_preshuffle_int4 (K pitch = K)
 
     @property
     def b_dtype(self) -> int:
-        return capi.I4_PACKED if self.bits == 4 else capi.I8
+        if self.bits == 4:
+            return capi.I4_PRESHUFFLED if self.layout == "preshuffled" else capi.I4_PACKED
+        return capi.I8
 
     @property
     def a_dtype(self) -> int:
@@ -115,6 +126,32 @@ def pack(q: np.ndarray, scale_bits: np.ndarray, bits: int = 4, scale_dtype: str 
     return PackedWeights(weight, scale_bits, bits, scale_dtype, N, K, group_k)
 
 
+def _preshuffled_unit_order(N: int, K: int) -> np.ndarray:
+    """dest[n, j] = index (in 16-byte units) at which the pre-shuffled layout keeps unit j (k = 32 j ..) of column n."""
+    n = np.arange(N)[:, None]
+    j = np.arange(K // 32)[None, :]
+    return (n // 32) * K + (j // 2) * 64 + 32 * ((n % 32) // 16) + 16 * (j % 2) + n % 16
+
+
+def preshuffle(pw: PackedWeights) -> PackedWeights:
+    """Packed int4 weights -> the pre-shuffled layout (through the library's host routine)."""
+    if pw.bits != 4 or pw.layout != "packed":
+        raise ValueError("preshuffle takes packed 4-bit weights")
+    if pw.N % 32 or pw.K % 64:
+        raise ValueError("the pre-shuffled layout needs N % 32 == 0 and K % 64 == 0")
+    w = capi.preshuffle_int4_host(pw.weight, pw.K, pw.N).reshape(pw.N, pw.K // 2)
+    return PackedWeights(w, pw.scale, pw.bits, pw.scale_dtype, pw.N, pw.K, pw.group_k, "preshuffled")
+
+
+def unshuffle(pw: PackedWeights) -> PackedWeights:
+    """Inverse of ``preshuffle`` (host side, for inspection and tests; the index map is restated here in numpy)."""
+    if pw.layout != "preshuffled":
+        return pw
+    units = np.ascontiguousarray(pw.weight).reshape(-1, 16)
+    w = units[_preshuffled_unit_order(pw.N, pw.K)].reshape(pw.N, pw.K // 2)
+    return PackedWeights(np.ascontiguousarray(w), pw.scale, pw.bits, pw.scale_dtype, pw.N, pw.K, pw.group_k, "packed")
+
+
 def unpack_int4(packed: np.ndarray, K: int) -> np.ndarray:
     """Inverse of the packed int4 layout (host side, for inspection and tests): uint8 (N, K//2) -> int8 (N, K).
     Inside each little-endian 32-bit word nibble p holds k = 8g + 2p (p < 4) or 8g + 2(p - 4) + 1 (p >= 4)."""
@@ -129,6 +166,7 @@ def unpack_int4(packed: np.ndarray, K: int) -> np.ndarray:
 
 def dequantize(pw: PackedWeights) -> np.ndarray:
     """fp32 (N, K) weights as the kernels see them: q * scale rounded to the scale's 16-bit type."""
+    pw = unshuffle(pw)
     q = unpack_int4(pw.weight, pw.K) if pw.bits == 4 else pw.weight
     s = _from_bits(pw.scale, pw.scale_dtype)
     s_nk = np.repeat(s.T, pw.group_k, axis=1) if pw.group_k else s[:, None]
@@ -137,7 +175,8 @@ def dequantize(pw: PackedWeights) -> np.ndarray:
 
 def save_packed(path: str, pw: PackedWeights) -> None:
     np.savez(path, format=np.array(FORMAT), bits=np.array(pw.bits), scale_dtype=np.array(pw.scale_dtype),
-             N=np.array(pw.N), K=np.array(pw.K), group_k=np.array(pw.group_k), weight=pw.weight, scale=pw.scale)
+             N=np.array(pw.N), K=np.array(pw.K), group_k=np.array(pw.group_k), layout=np.array(pw.layout), weight=pw.weight,
+             scale=pw.scale)
 
 
 def load_packed(path: str) -> PackedWeights:
@@ -145,7 +184,10 @@ def load_packed(path: str) -> PackedWeights:
         if str(z["format"]) not in FORMATS_READ:
             raise ValueError(f"{path}: not a {FORMAT} container")
         pw = PackedWeights(z["weight"], z["scale"], int(z["bits"]), str(z["scale_dtype"]), int(z["N"]), int(z["K"]),
-                           int(z["group_k"]) if "group_k" in z.files else 0)
+                           int(z["group_k"]) if "group_k" in z.files else 0,
+                           str(z["layout"]) if "layout" in z.files else "packed")
+    if pw.layout not in LAYOUTS or (pw.layout == "preshuffled" and (pw.bits != 4 or pw.N % 32 or pw.K % 64)):
+        raise ValueError(f"{path}: layout {pw.layout!r} does not go with bits = {pw.bits}, N = {pw.N}, K = {pw.K}")
     want = (pw.N, pw.K // 2) if pw.bits == 4 else (pw.N, pw.K)
     want_s = (pw.K // pw.group_k, pw.N) if pw.group_k > 0 else (pw.N,)
     if pw.group_k < 0 or (pw.group_k and pw.K % pw.group_k) or pw.weight.shape != want or pw.scale.shape != want_s:

@@ -38,7 +38,8 @@ typedef enum wq_dtype
     WQ_U8_OFFSET = 5, /* uint8 = int8 + 128 (example/64_fpAintB_gemm/common.hpp:51-83)               */
     WQ_I4_PACKED = 6, /* two offset-binary nibbles per byte, layout documented at wqgemm_pack_int4   */
     WQ_I32       = 7,
-    WQ_F8_E4M3FN = 8  /* OCP E4M3 ("e4m3fn") bytes, bias 7, 0x7F/0xFF = NaN: the fp8 the gfx950 matrix core decodes; no counterpart in the reference, whose f8_t is FNUZ only */
+    WQ_F8_E4M3FN = 8, /* OCP E4M3 ("e4m3fn") bytes, bias 7, 0x7F/0xFF = NaN: the fp8 the gfx950 matrix core decodes; no counterpart in the reference, whose f8_t is FNUZ only */
+    WQ_I4_PRESHUFFLED = 9 /* WQ_I4_PACKED's nibbles with its 16-byte units (32 consecutive k of one column) stored in the order the 256-tile kernels consume them; layout documented at wqgemm_preshuffle_int4 */
 } wq_dtype;
 
 typedef enum wq_layout
@@ -233,6 +234,22 @@ int wqgemm_pack_int4(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t
  * WQ_ERR_INVALID if a value lies outside -8..7. */
 int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t* out,
                           int32_t ld_bytes);
+
+/* Re-order WQ_I4_PACKED weights (column n at packed + n*ld_bytes) into WQ_I4_PRESHUFFLED, the offline layout whose
+ * every wave-wide weight fetch of the 256-tile kernels is one contiguous kilobyte (the role of the pre-shuffled B of
+ * example/65_gemm_multiply_multiply's newer drivers; the reference tree here has no int4 form of it).  The unit that
+ * moves is 16 bytes = the 32 consecutive k [32j, 32j+32) of one column, nibble order inside it as in WQ_I4_PACKED.
+ * Block (cb, kb) = columns [32cb, 32cb+32) x k [64kb, 64kb+64) = 64 units = 1024 bytes at
+ *     out + cb * (ldk * 16) + kb * 1024,
+ * and inside a block the unit of column 32cb + 16t + r (t = 0, 1; r = 0..15), k half h (k = 64kb + 32h ..) sits at
+ * byte (32t + 16h + r) * 16.  ldk (elements, a multiple of 64, >= K) is the K pitch: wqgemm_problem.ldb of the GEMM
+ * that consumes the result.  Needs N % 32 == 0 and K % 64 == 0.  Device memory, asynchronous on `stream`. */
+int wqgemm_preshuffle_int4(const uint8_t* packed, int32_t ld_bytes, int32_t K, int32_t N, uint8_t* out, int32_t ldk,
+                           void* stream);
+
+/* Host-memory variant of wqgemm_preshuffle_int4 for offline weight preparation. */
+int wqgemm_preshuffle_int4_host(const uint8_t* packed, int32_t ld_bytes, int32_t K, int32_t N, uint8_t* out,
+                                int32_t ldk);
 
 /* Sum k_batch fp32 partials [k_batch][M][N] (row-major, ld = N) in ascending batch order, apply
  * p's epilogue and store p->c.  With k_batch == 1 this is the final convert/epilogue step after

@@ -103,6 +103,7 @@ class Checker:
             self._reduce = sig("splitk_reduce_f16", None, [_f32p, C.c_int, C.c_int, C.c_int, _u16p, C.c_int])
             self._pack = sig("pack_int4", C.c_int, [_i8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int])
             self._unpack = sig("unpack_int4", C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, _i8p, C.c_int])
+            self._preshuffle = sig("preshuffle_int4", C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int])
             self._offs = sig("offset_u8", None, [_i8p, _u8p, C.c_size_t])
 
     # -- generators ---------------------------------------------------------------------------
@@ -205,6 +206,15 @@ class Checker:
         rc = self._pack(np.ascontiguousarray(q).ravel(), ldq, K, N, out.reshape(-1), K // 2)
         if rc != 0:
             raise ValueError("pack_int4: K must be a multiple of 8 and values within -8..7")
+        return out
+
+    def preshuffle_int4(self, packed: np.ndarray, K: int, N: int, ldk: int | None = None) -> np.ndarray:
+        """packed: (N, K//2) uint8 in the packed int4 order -> flat uint8 in the pre-shuffled order (K pitch ldk)."""
+        ldk = ldk or K
+        out = np.zeros(N * ldk // 2, dtype=np.uint8)
+        rc = self._preshuffle(np.ascontiguousarray(packed).reshape(-1), K // 2, K, N, out, ldk)
+        if rc != 0:
+            raise ValueError("preshuffle_int4: K % 64, N % 32, ldk % 64 must be 0 and ldk >= K")
         return out
 
     def unpack_int4(self, packed: np.ndarray, K: int, N: int) -> np.ndarray:

@@ -690,6 +690,28 @@ int wqo_pack_int4(const int8_t* q, int ldq, int K, int N, uint8_t* out, int ld_b
     return 0;
 }
 
+/* The pre-shuffled order of the packed int4 weights (this engine's offline format for its 256-tile kernels; the
+ * reference tree has no int4 counterpart).  Written from the format's definition, element by element: the nibble of
+ * (k, n) keeps its position inside its 16-byte unit (the 32 consecutive k from 32 * (k / 32) of column n), and the unit
+ * moves to
+ *   (n / 32) * (ldk * 16)  +  (k / 64) * 1024  +  (32 * ((n % 32) / 16) + 16 * ((k % 64) / 32) + n % 16) * 16
+ * bytes from the start (ldk = K pitch in elements, a multiple of 64).  Returns 0, or -1 on bad sizes. */
+int wqo_preshuffle_int4(const uint8_t* packed, int ld_bytes, int K, int N, uint8_t* out, int ldk)
+{
+    if(K % 64 != 0 || N % 32 != 0 || ldk % 64 != 0 || ldk < K)
+        return -1;
+    for(int n = 0; n < N; ++n)
+        for(int k = 0; k < K; k += 2) /* one byte holds two nibbles; byte index inside the unit is kept */
+        {
+            const int byte_in_col  = k / 8 * 4 + (k % 8) / 2; /* little-endian word k / 8, byte (k % 8) / 2 of it */
+            const int byte_in_unit = byte_in_col % 16;
+            const size_t dst       = (size_t)(n / 32) * ((size_t)ldk * 16) + (size_t)(k / 64) * 1024 +
+                               (size_t)(32 * ((n % 32) / 16) + 16 * ((k % 64) / 32) + n % 16) * 16 + byte_in_unit;
+            out[dst] = packed[(size_t)n * ld_bytes + byte_in_col];
+        }
+    return 0;
+}
+
 int wqo_unpack_int4(const uint8_t* in, int ld_bytes, int K, int N, int8_t* q, int ldq)
 {
     if(K % 8 != 0)

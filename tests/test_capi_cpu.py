@@ -223,6 +223,45 @@ def test_ck_factory_registrations_link():
     assert r.stdout.count("DeviceGemmSplitK_WeightQuant_gfx950") == 4
 
 
+def test_preshuffle_int4_host_matches_checker(port):
+    """The pre-shuffled weight order: the library's host re-layout against the checker's element-wise statement of the
+    format, with and without a padded K pitch; bad sizes refused."""
+    rng = np.random.default_rng(3)
+    for K, N in ((64, 32), (256, 96), (128, 256)):
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        packed = port.pack_int4(q, K, N)
+        np.testing.assert_array_equal(capi.preshuffle_int4_host(packed, K, N), port.preshuffle_int4(packed, K, N))
+    K, N, ldk = 128, 64, 192
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    packed = port.pack_int4(q, K, N)
+    out = np.zeros(N * ldk // 2, np.uint8)
+    capi.check(capi.lib.wqgemm_preshuffle_int4_host(packed.ctypes.data, K // 2, K, N, out.ctypes.data, ldk))
+    np.testing.assert_array_equal(out, port.preshuffle_int4(packed, K, N, ldk))
+    for bad_k, bad_n, bad_ldk in ((96, 32, 96), (64, 48, 64), (64, 32, 32), (64, 32, 96)):
+        assert capi.lib.wqgemm_preshuffle_int4_host(packed.ctypes.data, bad_k // 2, bad_k, bad_n, out.ctypes.data,
+                                                    bad_ldk) == capi.ERR_INVALID
+
+
+def test_preshuffled_weights_routes():
+    # consumed by the 256-tile kernels, whatever M is; nothing else reads the layout and nothing falls back silently
+    pre = dict(b_dtype=capi.I4_PRESHUFFLED)
+    assert capi.kernel_name(_problem(**pre)) == "wq_gemm_mfma_256"
+    assert "I4_PRESHUFFLED" in capi.type_string(_problem(**pre))
+    assert capi.kernel_name(_problem(M=8, **pre)) == "wq_gemm_mfma_256"        # (the small-M kernels read the packed order)
+    assert capi.kernel_name(_problem(M=512, N=512, **pre)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(a_dtype=capi.BF16, **pre)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(scale_group_k=128, **pre)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(flags=capi.FLAG_GENERIC, **pre)) == "wq_gemm_generic"
+    assert not capi.is_supported(_problem(N=4096 + 128, **pre))                 # N % 256 != 0: no kernel
+    assert b"256-tile" in capi.lib.wqgemm_last_error()
+    assert not capi.is_supported(_problem(N=4096 + 16, **pre))                  # N % 32 != 0: not even a layout
+    assert not capi.is_supported(_problem(K=4096 + 32, ldb=4096 + 64, **pre))   # K % 64 != 0
+    assert not capi.is_supported(_problem(ldb=4096 + 32, **pre))                # K pitch must be whole 64-k blocks
+    assert capi.is_supported(_problem(ldb=4096 + 64, **pre))
+    assert not capi.is_supported(_problem(flags=capi.FLAG_TILE_128, **pre))
+    assert not capi.is_supported(_problem(scale_group_k=32, **pre))             # groups the tile kernels cannot take
+
+
 def test_group_wise_scale_validation_and_routes():
     # groups of a multiple of 64 k: the matrix-core kernels; anything else: the general kernel
     assert capi.kernel_name(_problem(scale_group_k=128)) == "wq_gemm_mfma_256"

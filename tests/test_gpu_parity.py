@@ -30,6 +30,112 @@ def test_pack_int4_device_bit_exact(port):
         np.testing.assert_array_equal(got, port.pack_int4(q, K, N))
 
 
+def preshuffle_on_device(packed: torch.Tensor, K: int, N: int, ldk: int | None = None) -> torch.Tensor:
+    ldk = ldk or K
+    out = torch.zeros(N * ldk // 2, dtype=torch.uint8, device="cuda")
+    capi.preshuffle_int4(packed.data_ptr(), K // 2, K, N, out.data_ptr(), ldk, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_preshuffle_int4_device_bit_exact(port):
+    rng = np.random.default_rng(1)
+    for K, N, ldk in ((64, 32, 64), (4096, 288, 4096), (128, 64, 192)):
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        packed = pack_on_device(q, K, N)
+        got = preshuffle_on_device(packed, K, N, ldk).cpu().numpy()
+        np.testing.assert_array_equal(got, port.preshuffle_int4(packed.cpu().numpy(), K, N, ldk))
+
+
+@pytest.mark.parametrize("a_dtype", [capi.F16, capi.BF16])
+def test_preshuffled_weights_equal_packed_weights(port, a_dtype):
+    """Pre-shuffled int4 weights feed the same dequantisation and the same MFMA order as packed ones: every variant of
+    the 256-tile kernel must return the packed run's bits on random (non-integer) data -- default and tuning
+    schedules, both wave grids, partial last row tile, split-K, a K slice that starts inside the matrix, a padded K
+    pitch, group-wise scales, the small-M case, and the general kernel reading the layout element by element; one case
+    against the checker."""
+    rng = np.random.default_rng(23)
+    bits = f16_bits if a_dtype == capi.F16 else bf16_bits
+    cases = [(256, 256, 256, 0, 1), (300, 512, 192, 0, 1), (512, 256, 512, capi.FLAG_LOCKSTEP, 1),
+             (256, 512, 256, capi.FLAG_WAVES_2X4, 1), (256, 256, 384, capi.FLAG_DEQUANT_IN_L, 1),
+             (256, 256, 256, capi.FLAG_WAVES_2X4 | capi.FLAG_DEQUANT_IN_L, 1), (256, 256, 512, 0, 2), (40, 256, 256, 0, 1),
+             (256, 256, 128, capi.FLAG_DIRECT_STORE, 1)]
+    for (M, N, K, flags, kb) in cases:
+        a = bits(rng.uniform(-1, 1, (M, K)))
+        s = bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        packed = pack_on_device(q, K, N)
+        pre = preshuffle_on_device(packed, K, N)
+        want = run_fpaintb(a, packed, s, M, N, K, a_dtype=a_dtype, flags=flags | capi.FLAG_TILE_256, k_batch=kb,
+                           expect_kernel=MFMA256)
+        got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, flags=flags, k_batch=kb,
+                          expect_kernel=MFMA256)
+        np.testing.assert_array_equal(got, want)
+    # against the checker, and the general kernel on the pre-shuffled bytes (bit-exact: ascending k)
+    M, N, K = 64, 256, 128
+    a = bits(rng.uniform(-1, 1, (M, K)))
+    s = bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    pre = preshuffle_on_device(pack_on_device(q, K, N), K, N)
+    gen = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, flags=capi.FLAG_GENERIC,
+                      expect_kernel=GENERIC)
+    if a_dtype == capi.F16:
+        exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    else:
+        exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+    np.testing.assert_array_equal(gen, exp)
+    got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, expect_kernel=MFMA256)
+    check_err(bits_to_f32(got, a_dtype), bits_to_f32(exp, a_dtype), 1e-2 if a_dtype == capi.BF16 else 1e-3, 1e-3)
+    # padded K pitch (ldb = K + 64) and a K slice [128, 384) of K = 512 into an fp32 partial
+    M, N, K, ldk = 256, 256, 512, 576
+    a = bits(rng.uniform(-1, 1, (M, K)))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    packed = pack_on_device(q, K, N)
+    pre = preshuffle_on_device(packed, K, N, ldk)
+    want = run_fpaintb(a, packed, s, M, N, K, a_dtype=a_dtype, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
+    got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, ldb=ldk, expect_kernel=MFMA256)
+    np.testing.assert_array_equal(got, want)
+    if a_dtype == capi.F16:
+        # group-wise scales (groups of 128 k)
+        sg = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, (K // 128, N)))
+        want = run_fpaintb(a, packed, sg, M, N, K, flags=capi.FLAG_TILE_256, scale_group_k=128, expect_kernel=MFMA256)
+        got = run_fpaintb(a, pre, sg, M, N, K, b_dtype=capi.I4_PRESHUFFLED, ldb=ldk, scale_group_k=128, expect_kernel=MFMA256)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_preshuffled_weights_fp8_kernel(port):
+    """The fp8 x int4 kernel on pre-shuffled weights: bit-equal to the packed run (same conversion, same MFMA order) on
+    random bytes, both byte formats, a partial last row tile and split-K; exact set against the checker."""
+    rng = np.random.default_rng(29)
+    for (M, N, K, kb) in ((256, 256, 128, 1), (300, 512, 512, 1), (512, 256, 1024, 2), (100, 256, 384, 1)):
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        packed = pack_on_device(q, K, N)
+        pre = preshuffle_on_device(packed, K, N)
+        d0 = rng.uniform(0.0, 1.0, N).astype(np.float32)
+        d1 = rng.uniform(0.0, 1.0, M).astype(np.float32)
+        a = _f8_bytes(rng, (M, K))
+        for adt, fl in ((capi.F8_FNUZ, capi.FLAG_F8_NO_SPECIALS), (capi.F8_E4M3FN, 0)):
+            kw = dict(a_dtype=adt, epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU, d0=d0, d1=d1, flags=fl, k_batch=kb,
+                      expect_kernel=F8_MFMA)
+            want = run_fpaintb(a, packed, None, M, N, K, **kw)
+            got = run_fpaintb(a, pre, None, M, N, K, b_dtype=capi.I4_PRESHUFFLED, **kw)
+            np.testing.assert_array_equal(got, want)
+    M, N, K = 256, 256, 256
+    lut = {0: 0x00, 1: 0x40, 2: 0x48, -1: 0xC0, -2: 0xC8}
+    a = np.vectorize(lut.get)(rng.integers(-2, 3, (M, K))).astype(np.uint8)
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    pre = preshuffle_on_device(pack_on_device(q, K, N), K, N)
+    d0e = (2.0 ** rng.integers(-3, 1, N)).astype(np.float32)
+    d1e = (2.0 ** rng.integers(-3, 1, M)).astype(np.float32)
+    got = run_fpaintb(a, pre, None, M, N, K, a_dtype=capi.F8_FNUZ, b_dtype=capi.I4_PRESHUFFLED, epilogue=capi.EPI_MULTIPLY_MULTIPLY,
+                      d0=d0e, d1=d1e, flags=capi.FLAG_F8_NO_SPECIALS, expect_kernel=F8_MFMA)
+    np.testing.assert_array_equal(got, port.gemm_f8_i8_mm(a, q, d0e, d1e, M, N, K, K, K, N, False).reshape(M, N))
+    # the four-section form reads weights through LDS in the packed order only
+    p = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, M, N, K, a_dtype=capi.F8_E4M3FN, b_dtype=capi.I4_PRESHUFFLED,
+                             c_dtype=capi.F16, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=1 << 20, d1=1 << 20, flags=capi.FLAG_PINGPONG)
+    assert not capi.is_supported(p)
+
+
 def test_mfma_layout_probe(port):
     """A = shifted identity pattern, B asymmetric: catches transposed / permuted fragment maps."""
     M = N = 128
@@ -1330,3 +1436,45 @@ def test_random_shapes_f8_int4_against_the_general_kernel():
         got = run_fpaintb(a, bp, None, M, N, K, flags=0 if fn else capi.FLAG_F8_NO_SPECIALS, expect_kernel=F8_MFMA, **kw)
         ref = run_fpaintb(a, bp, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC, **kw)
         np.testing.assert_array_equal(got, ref, err_msg=f"case {case}: M={M} N={N} K={K} e4m3fn={fn}")
+
+
+def test_torch_linear_preshuffled_weights(tmp_path):
+    """Pre-shuffled int4 weights through the container and the torch operator: the same bits as the packed layout of
+    the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch; shapes the 256-tile
+    kernels cannot take are refused, not run slowly."""
+    from composable_kernel_amd import weights
+    from composable_kernel_amd.torch_ops import WqLinear
+    rng = np.random.default_rng(31)
+    N, K = 512, 1024
+    w = rng.normal(0, 0.05, (N, K)).astype(np.float32)
+    q, s = weights.quantize_per_channel(w, 4, "f16")
+    pk = weights.pack(q, s, 4, "f16")
+    path = str(tmp_path / "pre.npz")
+    weights.save_packed(path, weights.preshuffle(pk))
+    pw = weights.load_packed(path)
+    assert pw.layout == "preshuffled" and pw.b_dtype == capi.I4_PRESHUFFLED
+    np.testing.assert_array_equal(weights.unshuffle(pw).weight, pk.weight)
+    np.testing.assert_array_equal(weights.dequantize(pw), weights.dequantize(pk))
+    lin_pre, lin_pk = WqLinear(pw), WqLinear(pk)
+    x = torch.from_numpy(rng.uniform(-1, 1, (300, K)).astype(np.float32)).half().cuda()
+    y = lin_pre(x)
+    wd = torch.from_numpy(weights.dequantize(pk)).double()
+    assert torch.allclose(y.cpu().double(), x.cpu().double() @ wd.T, rtol=2e-3, atol=2e-3)
+    # the packed layer takes the 128-tile kernel at this size (a short grid); force it onto the same kernel for the bit comparison
+    from composable_kernel_amd.torch_ops import fpaintb_linear
+    for rows in (300, 5):
+        xs = x[:rows].contiguous()
+        yp = lin_pre(xs)
+        c = torch.empty((rows, N), dtype=torch.float16, device="cuda")
+        p = capi.fpAintB_problem(xs.data_ptr(), lin_pk.weight.data_ptr(), lin_pk.scale.data_ptr(), c.data_ptr(), rows, N, K,
+                                 flags=capi.FLAG_TILE_256)
+        capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(yp, c)
+    # N = 384 is not a whole number of 256-column tiles
+    q2, s2 = weights.quantize_per_channel(w[:384], 4, "f16")
+    lin = WqLinear(weights.preshuffle(weights.pack(q2, s2, 4, "f16")))
+    with pytest.raises((ValueError, RuntimeError)):
+        lin(x)
+    with pytest.raises(ValueError):
+        fpaintb_linear(x, lin_pre.weight, lin_pre.scale, 8, "none", None, "preshuffled")

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--variants", default="0,4,1")
     ap.add_argument("--a", default="f16", choices=["f16", "bf16", "f8", "f8fnuz"])
     ap.add_argument("--ramp", type=int, default=1000, help="untimed launches before timing (clock settling)")
-    ap.add_argument("--b", default="i4", choices=["i4", "i8", "u8"])
+    ap.add_argument("--b", default="i4", choices=["i4", "i4pre", "i8", "u8"], help="i4pre: packed int4 in the pre-shuffled order")
     ap.add_argument("--group-k", type=int, default=0, help="group-wise weight scales: k per group (fp16 activations)")
     args = ap.parse_args()
     M, N, K = args.M, args.N, args.K
@@ -46,11 +46,15 @@ def main():
         a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).to(adt)
     s_rows = K // args.group_k if args.group_k else 1
     s = (torch.rand((s_rows, N), generator=g, device=dev) * (2.0 ** -4 - 2.0 ** -8) + 2.0 ** -8).to(adt)
-    if args.b == "i4":
+    if args.b in ("i4", "i4pre"):
         q = torch.randint(-8, 8, (N, K), generator=g, device=dev, dtype=torch.int8)
         b = torch.empty((N, K // 2), dtype=torch.uint8, device=dev)
         capi.pack_int4(q.data_ptr(), K, K, N, b.data_ptr(), K // 2, torch.cuda.current_stream().cuda_stream)
         bdt = capi.I4_PACKED
+        if args.b == "i4pre":
+            b2 = torch.empty_like(b)
+            capi.preshuffle_int4(b.data_ptr(), K // 2, K, N, b2.data_ptr(), K, torch.cuda.current_stream().cuda_stream)
+            b, bdt = b2, capi.I4_PRESHUFFLED
     else:
         b = torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8)
         bdt = capi.I8 if args.b == "i8" else capi.U8_OFFSET
