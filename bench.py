@@ -220,14 +220,17 @@ def workload_c3(dev):
     a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).bfloat16()
     s = (torch.rand((N,), generator=g, device=dev) * (2.0 ** -6 - 2.0 ** -10) + 2.0 ** -10).bfloat16()
     b = torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8)
+    bpre = torch.empty_like(b)  # the same bytes in the engine's pre-shuffled order (offline step; same output bits)
+    capi.preshuffle_int8(b.data_ptr(), K, K, N, bpre.data_ptr(), K, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     c = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 
     def prob(a_, b_, c_):
         return capi.fpAintB_problem(a_.data_ptr(), b_.data_ptr(), s.data_ptr(), c_.data_ptr(), M, N, K,
-                                    a_dtype=capi.BF16, b_dtype=capi.I8)
+                                    a_dtype=capi.BF16, b_dtype=capi.I8_PRESHUFFLED)
 
     def clone():
-        t = (a.clone(), b.clone(), torch.empty_like(c))
+        t = (a.clone(), bpre.clone(), torch.empty_like(c))
         return t, prob(*t)
 
     def cpu(budget_s):
@@ -252,11 +255,11 @@ def workload_c3(dev):
                           f"full-size estimate {dt * M / rows:.0f} s",
                 "gpu_rows_match_checker": ok, "max_abs_err": float(err.max())}
 
-    return {"M": M, "N": N, "K": K, "problem": prob(a, b, c), "keep": (a, b, s, c), "clone": clone, "cpu": cpu,
+    return {"M": M, "N": N, "K": K, "problem": prob(a, bpre, c), "keep": (a, b, bpre, s, c), "clone": clone, "cpu": cpu,
             "dtype": "bf16", "peak": PEAK_FP16_MFMA_TFLOPS, "bytes": 2 * M * K + K * N + 2 * N + 2 * M * N,
             "workspace": None,
             "workload": "bf16A x int8B GEMM M=4096 N=11008 K=4096, per-channel bf16 scale (Multiply on B), bf16 C "
-                        "(example/60_gemm_multi_ABD arithmetic, BASELINE config 3)"}
+                        "(example/60_gemm_multi_ABD arithmetic, BASELINE config 3); int8 weights in the pre-shuffled order"}
 
 
 def workload_c5(dev):

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("WQGEMM_LIB") or os.path.join(HERE, "csrc", "libwqgemm
 # wq_status
 OK, ERR_UNSUPPORTED, ERR_INVALID, ERR_HIP, ERR_WORKSPACE = range(5)
 # wq_dtype
-F16, BF16, F8_FNUZ, F32, I8, U8_OFFSET, I4_PACKED, I32, F8_E4M3FN, I4_PRESHUFFLED = range(10)
+F16, BF16, F8_FNUZ, F32, I8, U8_OFFSET, I4_PACKED, I32, F8_E4M3FN, I4_PRESHUFFLED, I8_PRESHUFFLED = range(11)
 # wq_layout
 ROW_MAJOR, COL_MAJOR = 0, 1
 # wqgemm_problem.flags
@@ -39,7 +39,7 @@ FLAG_PINGPONG = 8192
 EXPORTS = (
     "wqgemm_version", "wqgemm_problem_size", "wqgemm_last_error", "wqgemm_is_supported", "wqgemm_workspace_bytes",
     "wqgemm_launch", "wqgemm_run_timed", "wqgemm_type_string", "wqgemm_kernel_name",
-    "wqgemm_pack_int4", "wqgemm_pack_int4_host", "wqgemm_preshuffle_int4", "wqgemm_preshuffle_int4_host", "wqgemm_reduce_finalize", "wqgemm_splitk_kread",
+    "wqgemm_pack_int4", "wqgemm_pack_int4_host", "wqgemm_preshuffle_int4", "wqgemm_preshuffle_int4_host", "wqgemm_preshuffle_int8", "wqgemm_preshuffle_int8_host", "wqgemm_reduce_finalize", "wqgemm_splitk_kread",
     "wqgemm_run_timed_rotating", "wqgemm_launch_noalloc", "wqgemm_splitk_multi_workspace_bytes",
     "wqgemm_splitk_multi_step",
 )
@@ -106,6 +106,10 @@ def _load() -> C.CDLL:
     L.wqgemm_preshuffle_int4.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.wqgemm_preshuffle_int4_host.restype = C.c_int
     L.wqgemm_preshuffle_int4_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+    L.wqgemm_preshuffle_int8.restype = C.c_int
+    L.wqgemm_preshuffle_int8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.wqgemm_preshuffle_int8_host.restype = C.c_int
+    L.wqgemm_preshuffle_int8_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
     L.wqgemm_pack_int4_host.restype = C.c_int
     L.wqgemm_pack_int4_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
     L.wqgemm_reduce_finalize.restype = C.c_int
@@ -201,6 +205,22 @@ def preshuffle_int4_host(packed, K: int, N: int):
     assert packed.shape == (N, K // 2)
     out = np.empty(N * K // 2, dtype=np.uint8)
     check(lib.wqgemm_preshuffle_int4_host(packed.ctypes.data, K // 2, K, N, out.ctypes.data, K))
+    return out
+
+
+def preshuffle_int8(b_ptr: int, ldb: int, K: int, N: int, out_ptr: int, ldk: int, stream: int | None = None) -> None:
+    """WQ_I8 -> WQ_I8_PRESHUFFLED on the device (layout: include/wqgemm.h, wqgemm_preshuffle_int8)."""
+    check(lib.wqgemm_preshuffle_int8(b_ptr, ldb, K, N, out_ptr, ldk, stream))
+
+
+def preshuffle_int8_host(b, K: int, N: int):
+    """b: numpy int8 (N, K), K contiguous -> flat numpy int8 of N * K bytes in WQ_I8_PRESHUFFLED order (ldk = K)."""
+    import numpy as np
+
+    b = np.ascontiguousarray(b, dtype=np.int8)
+    assert b.shape == (N, K)
+    out = np.empty(N * K, dtype=np.int8)
+    check(lib.wqgemm_preshuffle_int8_host(b.ctypes.data, K, K, N, out.ctypes.data, K))
     return out
 
 

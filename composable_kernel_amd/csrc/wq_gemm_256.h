@@ -245,6 +245,23 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
                 raw_off[s] = (col_w >> 5) * 1024 + (s * 16 + fr) * 16 + fq * 4;
         }
     }
+    else
+    {
+        // Pre-shuffled 8-bit weights: a DMA piece (16 columns x 64 k) is one contiguous KiB whose 16-byte units sit
+        // column after column, k quarter after k quarter; the lane that fills LDS slot l fetches the unit the swizzled
+        // image wants there (column l / 4, k quarter (l % 4) ^ swizzle), so the image and its reads do not change.
+        if(p.b_preshuf)
+        {
+#pragma unroll
+            for(int i = 0; i < T::B_DMA; ++i)
+            {
+                const int c = lane >> 2, j = (lane & 3) ^ ((c >> 2) & 3);
+                b_src[i]    = (const uint8_t*)p.b + (size_t)((n0 >> 4) + wave * T::B_DMA + i) * ((size_t)p.ldb_bytes * 16) +
+                           (size_t)(kz_begin >> 6) * 1024 + (c * 4 + j) * 16;
+            }
+            b_tile_stride = 1024;
+        }
+    }
 
     auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         uint8_t* sa = lds + buf * T::STAGE;

@@ -38,9 +38,15 @@ struct GemmParams
     EpilogueArgs epi;
     int scale_group_k; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
     int ld_scale;
-    int b_preshuf;     // packed int4 weights in the pre-shuffled order (blocks of 32 columns x 64 k = 1 KiB; column-block
-                       // pitch = 32 * ldb_bytes): 256-tile kernels only
+    int b_preshuf;     // weights in the pre-shuffled order (1 KiB blocks of 64 k x 32 columns of packed int4 or x 16
+                       // columns of int8; column-block pitch = 32 * ldb_bytes or 16 * ldb_bytes): 256-tile kernels only
 };
+
+// Byte offset of the 16-byte unit (16 consecutive k from 16 * k16 of column n) inside pre-shuffled 8-bit weights.
+__host__ __device__ __forceinline__ size_t preshuf8_unit_offset(int n, int k16, int ldb_bytes)
+{
+    return (size_t)(n >> 4) * ((size_t)ldb_bytes * 16) + (size_t)(k16 >> 2) * 1024 + (size_t)(((n & 15) * 4 + (k16 & 3)) * 16);
+}
 
 // Byte offset of the 16-byte unit (32 consecutive k from 32 * k32 of column n) inside pre-shuffled int4 weights.
 __host__ __device__ __forceinline__ size_t preshuf_unit_offset(int n, int k32, int ldb_bytes)
@@ -906,6 +912,8 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
             const int pos    = (j & 1) ? 4 + (j >> 1) : (j >> 1);
             q                = (int)((w >> (4 * pos)) & 0xFu) - 8;
         }
+        else if(p.b_dtype == 10 /*WQ_I8_PRESHUFFLED*/)
+            q = (int)((const int8_t*)p.b)[preshuf8_unit_offset(n, k >> 4, (int)p.b_sn) + (k & 15)];
         else if(p.b_dtype == 5 /*WQ_U8_OFFSET*/)
             q = (int)((const uint8_t*)p.b)[k * p.b_sk + n * p.b_sn] - 128;
         else
@@ -1024,6 +1032,24 @@ __global__ __launch_bounds__(256) void wq_preshuffle_int4(const uint8_t* __restr
         const int n = cb * 32 + (u >> 5) * 16 + (u & 15), k32 = kb * 2 + ((u >> 4) & 1);
         const u4_t v = *(const u4_t*)(packed + (size_t)n * ld_bytes + (size_t)k32 * 16);
         *(u4_t*)(out + preshuf_unit_offset(n, k32, ldb_bytes_out)) = v;
+    }
+}
+
+// int8 (K contiguous per column) -> pre-shuffled int8: one thread per 16-byte unit (16 consecutive k of one column).
+__global__ __launch_bounds__(256) void wq_preshuffle_int8(const uint8_t* __restrict__ b, int ldb, int K, int N,
+                                                          uint8_t* __restrict__ out, int ldb_out)
+{
+    const int units  = K >> 4;
+    const long total = (long)N * units;
+    for(long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    {
+        const long blk = i >> 6;
+        const int u    = (int)(i & 63);
+        const int kbs  = K >> 6;
+        const int cb = (int)(blk / kbs), kb = (int)(blk % kbs);
+        const int n = cb * 16 + (u >> 2), k16 = kb * 4 + (u & 3);
+        const u4_t v = *(const u4_t*)(b + (size_t)n * ldb + (size_t)k16 * 16);
+        *(u4_t*)(out + preshuf8_unit_offset(n, k16, ldb_out)) = v;
     }
 }
 

@@ -86,6 +86,7 @@ struct Plan
 
 bool is16(int dt) { return dt == WQ_F16 || dt == WQ_BF16; }
 bool is_i4(int dt) { return dt == WQ_I4_PACKED || dt == WQ_I4_PRESHUFFLED; } // two nibbles per byte, either unit order
+bool is_preshuf(int dt) { return dt == WQ_I4_PRESHUFFLED || dt == WQ_I8_PRESHUFFLED; }
 
 // Epilogues of the floating-point family and the D vectors each one reads.
 int check_fp_epilogue(const wqgemm_problem* p)
@@ -199,16 +200,17 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // ---- fpAintB family ------------------------------------------------------------------------
     if(p->a_dtype != WQ_F16 && p->a_dtype != WQ_BF16 && p->a_dtype != WQ_F8_FNUZ && p->a_dtype != WQ_F8_E4M3FN)
         return fail(WQ_ERR_UNSUPPORTED, "unsupported A dtype %d", p->a_dtype);
-    if(!is_i4(p->b_dtype) && p->b_dtype != WQ_U8_OFFSET && p->b_dtype != WQ_I8)
+    if(!is_i4(p->b_dtype) && p->b_dtype != WQ_U8_OFFSET && p->b_dtype != WQ_I8 && p->b_dtype != WQ_I8_PRESHUFFLED)
         return fail(WQ_ERR_UNSUPPORTED, "unsupported B dtype %d", p->b_dtype);
     if(is_i4(p->b_dtype) && (p->b_layout != WQ_COL_MAJOR || p->K % 8 != 0 || p->ldb % 8 != 0))
         return fail(WQ_ERR_UNSUPPORTED,
                     "packed int4 B must be column-major (K contiguous) with K and ldb multiples of 8");
     if(is_i4(p->b_dtype) && (plan.k_begin % 8 != 0 || plan.k_per_z % 8 != 0))
         return fail(WQ_ERR_UNSUPPORTED, "packed int4 K slices must start on multiples of 8");
-    const bool preshuf = p->b_dtype == WQ_I4_PRESHUFFLED;
-    if(preshuf && (p->N % 32 != 0 || p->K % 64 != 0 || p->ldb % 64 != 0 || plan.k_begin % 64 != 0 || plan.k_per_z % 64 != 0))
-        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled int4 B: N must be a multiple of 32; K, ldb and K slices multiples of 64");
+    const bool preshuf = is_preshuf(p->b_dtype);
+    if(preshuf && (p->b_layout != WQ_COL_MAJOR || p->N % 32 != 0 || p->K % 64 != 0 || p->ldb % 64 != 0 || p->ldb < p->K ||
+                   plan.k_begin % 64 != 0 || plan.k_per_z % 64 != 0))
+        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled B: column-major, N a multiple of 32; K, ldb and K slices multiples of 64");
     if(is16(p->a_dtype))
     {
         if(p->scale && p->scale_dtype != p->a_dtype)
@@ -381,10 +383,10 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // for by name); there is no slow path to fall onto silently.
     if(preshuf && plan.route != ROUTE_MFMA256 && plan.route != ROUTE_F8_MFMA256 && !(p->flags & WQ_FLAG_GENERIC))
         return fail(WQ_ERR_UNSUPPORTED,
-                    "pre-shuffled int4 B runs on the 256-tile kernels only: N %% 256 == 0, K in whole 64-k tiles (128 for fp8 "
+                    "pre-shuffled B runs on the 256-tile kernels only: N %% 256 == 0, K in whole 64-k tiles (128 for fp8 "
                     "activations), K-contiguous 16-byte aligned operands, default wave grid");
     if(preshuf && (p->flags & (WQ_FLAG_MFMA_32X32 | WQ_FLAG_TILE_128)))
-        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled int4 B: no 128-tile or 32x32-MFMA kernel reads this layout");
+        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled B: no 128-tile or 32x32-MFMA kernel reads this layout");
     if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)
         return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs N to be a multiple of 256 and tile-aligned operands");
     if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_MFMA128)
@@ -458,7 +460,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.K         = p->K;
         if(!plan.via_colb)
             gp.ldb_bytes = is_i4(p->b_dtype) ? p->ldb / 2 : p->ldb;
-        gp.b_preshuf = p->b_dtype == WQ_I4_PRESHUFFLED ? 1 : 0;
+        gp.b_preshuf = is_preshuf(p->b_dtype) ? 1 : 0;
         gp.ldc       = ld_out;
         gp.k_begin   = plan.k_begin;
         gp.k_end     = plan.k_end;
@@ -674,6 +676,7 @@ const char* dt_name(int dt)
     case WQ_U8_OFFSET: return "U8";
     case WQ_I4_PACKED: return "I4";
     case WQ_I4_PRESHUFFLED: return "I4_PRESHUFFLED";
+    case WQ_I8_PRESHUFFLED: return "I8_PRESHUFFLED";
     case WQ_I32: return "I32";
     default: return "?";
     }
@@ -1055,6 +1058,36 @@ int wqgemm_preshuffle_int4(const uint8_t* packed, int32_t ld_bytes, int32_t K, i
     hipLaunchKernelGGL(wq::wq_preshuffle_int4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, ld_bytes, K, N, out,
                        ldk / 2);
     WQ_HIP(hipGetLastError());
+    return WQ_OK;
+}
+
+int wqgemm_preshuffle_int8(const int8_t* b, int32_t ldb, int32_t K, int32_t N, int8_t* out, int32_t ldk, void* stream)
+{
+    if(!b || !out)
+        return fail(WQ_ERR_INVALID, "null pointer");
+    if(K <= 0 || N <= 0 || K % 64 != 0 || N % 16 != 0 || ldb < K || ldb % 16 != 0 || ldk < K || ldk % 64 != 0 ||
+       (uintptr_t)b % 16 != 0 || (uintptr_t)out % 16 != 0)
+        return fail(WQ_ERR_INVALID, "preshuffle_int8: need K %% 64 == 0, N %% 16 == 0, 16-byte aligned columns (ldb %% 16 == 0, "
+                                    "ldb >= K), ldk >= K, ldk %% 64 == 0");
+    const long work = (long)N * (K / 16);
+    int blocks      = (int)((work + 255) / 256);
+    if(blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(wq::wq_preshuffle_int8, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)b, ldb, K, N,
+                       (uint8_t*)out, ldk);
+    WQ_HIP(hipGetLastError());
+    return WQ_OK;
+}
+
+int wqgemm_preshuffle_int8_host(const int8_t* b, int32_t ldb, int32_t K, int32_t N, int8_t* out, int32_t ldk)
+{
+    if(!b || !out)
+        return fail(WQ_ERR_INVALID, "null pointer");
+    if(K <= 0 || N <= 0 || K % 64 != 0 || N % 16 != 0 || ldb < K || ldk < K || ldk % 64 != 0)
+        return fail(WQ_ERR_INVALID, "preshuffle_int8_host: need K %% 64 == 0, N %% 16 == 0, ldb >= K, ldk >= K, ldk %% 64 == 0");
+    for(int n = 0; n < N; ++n)
+        for(int k16 = 0; k16 < K / 16; ++k16)
+            memcpy(out + wq::preshuf8_unit_offset(n, k16, ldk), b + (size_t)n * ldb + (size_t)k16 * 16, 16);
     return WQ_OK;
 }
 

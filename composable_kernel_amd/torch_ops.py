@@ -21,7 +21,7 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
                    bias: torch.Tensor | None, layout: str = "packed") -> torch.Tensor:
     """y[m, n] = epilogue( sum_k x[m, k] * dequant(weight[n, k], scale[n]) [, bias[n]] ).
 
-    layout = "preshuffled" (bits = 4): the weight bytes are in the order of wqgemm_preshuffle_int4; runs on the 256-tile
+    layout = "preshuffled": the weight bytes are in the order of wqgemm_preshuffle_int4 / _int8; runs on the 256-tile
     kernels only (N a multiple of 256, K of 64) and raises where they cannot take the problem.
 
     x (M, K) fp16 / bf16, row-major; weight uint8 (N, K/2) packed int4 (bits = 4) or int8 (N, K) (bits = 8);
@@ -37,8 +37,8 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
         raise ValueError("bias goes with the add / add_fastgelu epilogues only")
     if bits not in (4, 8):
         raise ValueError(f"bits must be 4 (packed int4) or 8 (int8), got {bits}")
-    if layout not in ("packed", "preshuffled") or (layout == "preshuffled" and bits != 4):
-        raise ValueError(f"layout must be 'packed', or 'preshuffled' with bits = 4, got {layout!r} with bits = {bits}")
+    if layout not in ("packed", "preshuffled"):
+        raise ValueError(f"layout must be 'packed' or 'preshuffled', got {layout!r}")
     if x.dim() != 2 or scale.dim() not in (1, 2):
         raise ValueError("x must be (M, K) and scale (N,) or (groups, N)")
     M, K = x.shape
@@ -70,7 +70,8 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     p = capi.fpAintB_problem(x.data_ptr(), weight.data_ptr(), scale.data_ptr(), y.data_ptr(), M, N, K,
                              a_dtype=_DT[x.dtype],
-                             b_dtype=(capi.I4_PRESHUFFLED if layout == "preshuffled" else capi.I4_PACKED) if bits == 4 else capi.I8,
+                             b_dtype=((capi.I4_PRESHUFFLED, capi.I8_PRESHUFFLED) if layout == "preshuffled"
+                                      else (capi.I4_PACKED, capi.I8))[bits == 8],
                              epilogue=_EPILOGUES[epilogue], d0=bias.data_ptr() if bias is not None else None,
                              scale_group_k=group_k)
     if not capi.is_supported(p):

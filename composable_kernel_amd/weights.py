@@ -12,8 +12,9 @@ array, one row of N scales per group: the (K, N) scale tensor of the reference's
 (library/include/ck/library/reference_tensor_operation/cpu/reference_fpAintB_gemm.hpp:62-127) with repeated rows
 collapsed, in the (K / block, N) shape of example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:126-152.
 
-Packed int4 weights can additionally be stored pre-shuffled (``preshuffle``; ``WQ_I4_PRESHUFFLED``, the layout documented
-at ``wqgemm_preshuffle_int4``): the same bytes with their 16-byte units (32 consecutive k of one column) in the order the
+Weights can additionally be stored pre-shuffled (``preshuffle``; ``WQ_I4_PRESHUFFLED`` / ``WQ_I8_PRESHUFFLED``, the layouts
+documented at ``wqgemm_preshuffle_int4`` / ``wqgemm_preshuffle_int8``): the same bytes with their 16-byte units (32 or 16
+consecutive k of one column) in the order the
 256-tile kernels fetch them, so that every wave-wide weight fetch is one contiguous kilobyte.  Such weights run on those
 kernels only (N a multiple of 256, K of 64).
 
@@ -53,7 +54,7 @@ class PackedWeights:
     def b_dtype(self) -> int:
         if self.bits == 4:
             return capi.I4_PRESHUFFLED if self.layout == "preshuffled" else capi.I4_PACKED
-        return capi.I8
+        return capi.I8_PRESHUFFLED if self.layout == "preshuffled" else capi.I8
 
     @property
     def a_dtype(self) -> int:
@@ -126,20 +127,27 @@ def pack(q: np.ndarray, scale_bits: np.ndarray, bits: int = 4, scale_dtype: str 
     return PackedWeights(weight, scale_bits, bits, scale_dtype, N, K, group_k)
 
 
-def _preshuffled_unit_order(N: int, K: int) -> np.ndarray:
-    """dest[n, j] = index (in 16-byte units) at which the pre-shuffled layout keeps unit j (k = 32 j ..) of column n."""
+def _preshuffled_unit_order(N: int, K: int, bits: int) -> np.ndarray:
+    """dest[n, j] = index (in 16-byte units) at which the pre-shuffled layout keeps unit j of column n (4 bits: unit j =
+    k from 32 j, blocks of 32 columns; 8 bits: k from 16 j, blocks of 16 columns)."""
     n = np.arange(N)[:, None]
-    j = np.arange(K // 32)[None, :]
-    return (n // 32) * K + (j // 2) * 64 + 32 * ((n % 32) // 16) + 16 * (j % 2) + n % 16
+    if bits == 4:
+        j = np.arange(K // 32)[None, :]
+        return (n // 32) * K + (j // 2) * 64 + 32 * ((n % 32) // 16) + 16 * (j % 2) + n % 16
+    j = np.arange(K // 16)[None, :]
+    return (n // 16) * K + (j // 4) * 64 + 4 * (n % 16) + j % 4
 
 
 def preshuffle(pw: PackedWeights) -> PackedWeights:
-    """Packed int4 weights -> the pre-shuffled layout (through the library's host routine)."""
-    if pw.bits != 4 or pw.layout != "packed":
-        raise ValueError("preshuffle takes packed 4-bit weights")
+    """Packed int4 or int8 weights -> the pre-shuffled layout (through the library's host routines)."""
+    if pw.layout != "packed":
+        raise ValueError("preshuffle takes weights in the packed layout")
     if pw.N % 32 or pw.K % 64:
         raise ValueError("the pre-shuffled layout needs N % 32 == 0 and K % 64 == 0")
-    w = capi.preshuffle_int4_host(pw.weight, pw.K, pw.N).reshape(pw.N, pw.K // 2)
+    if pw.bits == 4:
+        w = capi.preshuffle_int4_host(pw.weight, pw.K, pw.N).reshape(pw.N, pw.K // 2)
+    else:
+        w = capi.preshuffle_int8_host(pw.weight, pw.K, pw.N).reshape(pw.N, pw.K)
     return PackedWeights(w, pw.scale, pw.bits, pw.scale_dtype, pw.N, pw.K, pw.group_k, "preshuffled")
 
 
@@ -148,7 +156,7 @@ def unshuffle(pw: PackedWeights) -> PackedWeights:
     if pw.layout != "preshuffled":
         return pw
     units = np.ascontiguousarray(pw.weight).reshape(-1, 16)
-    w = units[_preshuffled_unit_order(pw.N, pw.K)].reshape(pw.N, pw.K // 2)
+    w = units[_preshuffled_unit_order(pw.N, pw.K, pw.bits)].reshape(pw.weight.shape)
     return PackedWeights(np.ascontiguousarray(w), pw.scale, pw.bits, pw.scale_dtype, pw.N, pw.K, pw.group_k, "packed")
 
 
@@ -186,7 +194,7 @@ def load_packed(path: str) -> PackedWeights:
         pw = PackedWeights(z["weight"], z["scale"], int(z["bits"]), str(z["scale_dtype"]), int(z["N"]), int(z["K"]),
                            int(z["group_k"]) if "group_k" in z.files else 0,
                            str(z["layout"]) if "layout" in z.files else "packed")
-    if pw.layout not in LAYOUTS or (pw.layout == "preshuffled" and (pw.bits != 4 or pw.N % 32 or pw.K % 64)):
+    if pw.layout not in LAYOUTS or (pw.layout == "preshuffled" and (pw.N % 32 or pw.K % 64)):
         raise ValueError(f"{path}: layout {pw.layout!r} does not go with bits = {pw.bits}, N = {pw.N}, K = {pw.K}")
     want = (pw.N, pw.K // 2) if pw.bits == 4 else (pw.N, pw.K)
     want_s = (pw.K // pw.group_k, pw.N) if pw.group_k > 0 else (pw.N,)

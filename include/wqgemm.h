@@ -39,7 +39,8 @@ typedef enum wq_dtype
     WQ_I4_PACKED = 6, /* two offset-binary nibbles per byte, layout documented at wqgemm_pack_int4   */
     WQ_I32       = 7,
     WQ_F8_E4M3FN = 8, /* OCP E4M3 ("e4m3fn") bytes, bias 7, 0x7F/0xFF = NaN: the fp8 the gfx950 matrix core decodes; no counterpart in the reference, whose f8_t is FNUZ only */
-    WQ_I4_PRESHUFFLED = 9 /* WQ_I4_PACKED's nibbles with its 16-byte units (32 consecutive k of one column) stored in the order the 256-tile kernels consume them; layout documented at wqgemm_preshuffle_int4 */
+    WQ_I4_PRESHUFFLED = 9, /* WQ_I4_PACKED's nibbles with its 16-byte units (32 consecutive k of one column) stored in the order the 256-tile kernels consume them; layout documented at wqgemm_preshuffle_int4 */
+    WQ_I8_PRESHUFFLED = 10 /* WQ_I8 bytes with their 16-byte units (16 consecutive k of one column) in that order; layout documented at wqgemm_preshuffle_int8 */
 } wq_dtype;
 
 typedef enum wq_layout
@@ -246,6 +247,14 @@ int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, ui
  * that consumes the result.  Needs N % 32 == 0 and K % 64 == 0.  Device memory, asynchronous on `stream`. */
 int wqgemm_preshuffle_int4(const uint8_t* packed, int32_t ld_bytes, int32_t K, int32_t N, uint8_t* out, int32_t ldk,
                            void* stream);
+
+/* The same for 8-bit weights: WQ_I8 (K contiguous per column, column n at b + n*ldb) -> WQ_I8_PRESHUFFLED.  The unit
+ * is 16 bytes = the 16 consecutive k [16j, 16j+16) of one column; block (cb, kb) = columns [16cb, 16cb+16) x
+ * k [64kb, 64kb+64) = 64 units = 1024 bytes at out + cb * (ldk * 16) + kb * 1024, and inside a block the unit of column
+ * 16cb + c, k quarter j (k = 64kb + 16j ..) sits at byte (4c + j) * 16.  ldk (a multiple of 64, >= K) is the K pitch:
+ * wqgemm_problem.ldb of the consuming GEMM.  Needs N % 16 == 0 and K % 64 == 0. */
+int wqgemm_preshuffle_int8(const int8_t* b, int32_t ldb, int32_t K, int32_t N, int8_t* out, int32_t ldk, void* stream);
+int wqgemm_preshuffle_int8_host(const int8_t* b, int32_t ldb, int32_t K, int32_t N, int8_t* out, int32_t ldk);
 
 /* Host-memory variant of wqgemm_preshuffle_int4 for offline weight preparation. */
 int wqgemm_preshuffle_int4_host(const uint8_t* packed, int32_t ld_bytes, int32_t K, int32_t N, uint8_t* out,

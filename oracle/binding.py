@@ -104,6 +104,7 @@ class Checker:
             self._pack = sig("pack_int4", C.c_int, [_i8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int])
             self._unpack = sig("unpack_int4", C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, _i8p, C.c_int])
             self._preshuffle = sig("preshuffle_int4", C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int])
+            self._preshuffle8 = sig("preshuffle_int8", C.c_int, [_i8p, C.c_int, C.c_int, C.c_int, _i8p, C.c_int])
             self._offs = sig("offset_u8", None, [_i8p, _u8p, C.c_size_t])
 
     # -- generators ---------------------------------------------------------------------------
@@ -215,6 +216,15 @@ class Checker:
         rc = self._preshuffle(np.ascontiguousarray(packed).reshape(-1), K // 2, K, N, out, ldk)
         if rc != 0:
             raise ValueError("preshuffle_int4: K % 64, N % 32, ldk % 64 must be 0 and ldk >= K")
+        return out
+
+    def preshuffle_int8(self, b: np.ndarray, K: int, N: int, ldk: int | None = None) -> np.ndarray:
+        """b: (N, K) int8, K contiguous -> flat int8 in the pre-shuffled order (K pitch ldk)."""
+        ldk = ldk or K
+        out = np.zeros(N * ldk, dtype=np.int8)
+        rc = self._preshuffle8(np.ascontiguousarray(b, dtype=np.int8).reshape(-1), K, K, N, out, ldk)
+        if rc != 0:
+            raise ValueError("preshuffle_int8: K % 64, N % 16, ldk % 64 must be 0 and ldk >= K")
         return out
 
     def unpack_int4(self, packed: np.ndarray, K: int, N: int) -> np.ndarray:

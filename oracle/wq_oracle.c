@@ -712,6 +712,20 @@ int wqo_preshuffle_int4(const uint8_t* packed, int ld_bytes, int K, int N, uint8
     return 0;
 }
 
+/* The pre-shuffled order of 8-bit weights, byte by byte from the format's definition: byte (k, n) keeps its position
+ * k % 16 inside its 16-byte unit, and the unit moves to
+ *   (n / 16) * (ldk * 16)  +  (k / 64) * 1024  +  (4 * (n % 16) + (k % 64) / 16) * 16. */
+int wqo_preshuffle_int8(const int8_t* b, int ldb, int K, int N, int8_t* out, int ldk)
+{
+    if(K % 64 != 0 || N % 16 != 0 || ldk % 64 != 0 || ldk < K)
+        return -1;
+    for(int n = 0; n < N; ++n)
+        for(int k = 0; k < K; ++k)
+            out[(size_t)(n / 16) * ((size_t)ldk * 16) + (size_t)(k / 64) * 1024 + (size_t)(4 * (n % 16) + (k % 64) / 16) * 16 +
+                k % 16] = b[(size_t)n * ldb + k];
+    return 0;
+}
+
 int wqo_unpack_int4(const uint8_t* in, int ld_bytes, int K, int N, int8_t* q, int ldq)
 {
     if(K % 8 != 0)

@@ -242,6 +242,20 @@ def test_preshuffle_int4_host_matches_checker(port):
                                                     bad_ldk) == capi.ERR_INVALID
 
 
+def test_preshuffle_int8_host_matches_checker(port):
+    rng = np.random.default_rng(4)
+    for K, N in ((64, 16), (256, 96), (128, 256)):
+        b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        np.testing.assert_array_equal(capi.preshuffle_int8_host(b, K, N), port.preshuffle_int8(b, K, N))
+    K, N, ldk = 128, 64, 192
+    b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    out = np.zeros(N * ldk, np.int8)
+    capi.check(capi.lib.wqgemm_preshuffle_int8_host(b.ctypes.data, K, K, N, out.ctypes.data, ldk))
+    np.testing.assert_array_equal(out, port.preshuffle_int8(b, K, N, ldk))
+    for bad_k, bad_n, bad_ldk in ((96, 32, 96), (64, 24, 64), (64, 32, 32), (64, 32, 96)):
+        assert capi.lib.wqgemm_preshuffle_int8_host(b.ctypes.data, bad_k, bad_k, bad_n, out.ctypes.data, bad_ldk) == capi.ERR_INVALID
+
+
 def test_preshuffled_weights_routes():
     # consumed by the 256-tile kernels, whatever M is; nothing else reads the layout and nothing falls back silently
     pre = dict(b_dtype=capi.I4_PRESHUFFLED)
@@ -260,6 +274,16 @@ def test_preshuffled_weights_routes():
     assert capi.is_supported(_problem(ldb=4096 + 64, **pre))
     assert not capi.is_supported(_problem(flags=capi.FLAG_TILE_128, **pre))
     assert not capi.is_supported(_problem(scale_group_k=32, **pre))             # groups the tile kernels cannot take
+    # 8-bit weights in their pre-shuffled order: the same rules; not an operand of the int8 x int8 requantised GEMM
+    pre8 = dict(b_dtype=capi.I8_PRESHUFFLED)
+    assert capi.kernel_name(_problem(a_dtype=capi.BF16, N=11008, **pre8)) == "wq_gemm_mfma_256"
+    assert "I8_PRESHUFFLED" in capi.type_string(_problem(**pre8))
+    assert capi.kernel_name(_problem(M=8, **pre8)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(flags=capi.FLAG_GENERIC, **pre8)) == "wq_gemm_generic"
+    assert not capi.is_supported(_problem(N=4096 + 128, **pre8))
+    assert not capi.is_supported(_problem(b_layout=capi.ROW_MAJOR, **pre8))
+    assert not capi.is_supported(_problem(a_dtype=capi.I8, c_dtype=capi.I8, scale=None, epilogue=capi.EPI_ACT_MUL_CLAMP,
+                                          requant=0.03, **pre8))
 
 
 def test_group_wise_scale_validation_and_routes():

@@ -103,6 +103,47 @@ def test_preshuffled_weights_equal_packed_weights(port, a_dtype):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("a_dtype", [capi.F16, capi.BF16])
+def test_preshuffled_int8_weights_equal_plain_int8(port, a_dtype):
+    """8-bit weights in their pre-shuffled order: the device re-layout against the checker's statement of the format,
+    and every variant of the 256-tile kernel bit-equal to the run on plain int8 weights (random data); the general
+    kernel on the pre-shuffled bytes against the checker."""
+    rng = np.random.default_rng(37)
+    bits = f16_bits if a_dtype == capi.F16 else bf16_bits
+
+    def pre8(q, K, N, ldk=None):
+        ldk = ldk or K
+        src = dev(q)
+        out = torch.zeros(N * ldk, dtype=torch.int8, device="cuda")
+        capi.preshuffle_int8(src.data_ptr(), K, K, N, out.data_ptr(), ldk, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), port.preshuffle_int8(q, K, N, ldk))
+        return out
+
+    for (M, N, K, flags, kb, ldk) in ((256, 256, 256, 0, 1, None), (300, 512, 192, 0, 1, None), (512, 256, 512, capi.FLAG_LOCKSTEP, 1, None),
+                                      (256, 512, 256, capi.FLAG_WAVES_2X4, 1, None), (256, 256, 384, capi.FLAG_DEQUANT_IN_L, 1, None),
+                                      (256, 256, 512, 0, 2, None), (40, 256, 256, 0, 1, 320)):
+        a = bits(rng.uniform(-1, 1, (M, K)))
+        s = bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+        q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        want = run_fpaintb(a, q, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8, flags=flags | capi.FLAG_TILE_256, k_batch=kb,
+                           expect_kernel=MFMA256)
+        got = run_fpaintb(a, pre8(q, K, N, ldk), s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8_PRESHUFFLED, ldb=ldk, flags=flags,
+                          k_batch=kb, expect_kernel=MFMA256)
+        np.testing.assert_array_equal(got, want)
+    M, N, K = 48, 256, 128
+    a = bits(rng.uniform(-1, 1, (M, K)))
+    s = bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+    gen = run_fpaintb(a, pre8(q, K, N), s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8_PRESHUFFLED, flags=capi.FLAG_GENERIC,
+                      expect_kernel=GENERIC)
+    if a_dtype == capi.F16:
+        exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+    else:
+        exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
+    np.testing.assert_array_equal(gen, exp)
+
+
 def test_preshuffled_weights_fp8_kernel(port):
     """The fp8 x int4 kernel on pre-shuffled weights: bit-equal to the packed run (same conversion, same MFMA order) on
     random bytes, both byte formats, a partial last row tile and split-K; exact set against the checker."""
@@ -1477,4 +1518,11 @@ def test_torch_linear_preshuffled_weights(tmp_path):
     with pytest.raises((ValueError, RuntimeError)):
         lin(x)
     with pytest.raises(ValueError):
-        fpaintb_linear(x, lin_pre.weight, lin_pre.scale, 8, "none", None, "preshuffled")
+        fpaintb_linear(x, lin_pre.weight, lin_pre.scale, 4, "none", None, "shuffled")
+    # 8-bit weights, bf16 activations
+    q8, s8 = weights.quantize_per_channel(w, 8, "bf16")
+    pk8 = weights.pack(q8, s8, 8, "bf16")
+    xb = x.to(torch.bfloat16)
+    y8 = WqLinear(weights.preshuffle(pk8))(xb)
+    wd8 = torch.from_numpy(weights.dequantize(pk8)).double()
+    assert torch.allclose(y8.cpu().double(), xb.cpu().double() @ wd8.T, rtol=1.6e-2, atol=1.6e-2)

@@ -94,9 +94,17 @@ def test_preshuffled_layout_roundtrip(tmp_path, port):
     assert back.layout == "preshuffled" and back.group_k == 64 and back.b_dtype == weights.capi.I4_PRESHUFFLED
     np.testing.assert_array_equal(weights.unshuffle(back).weight, pk.weight)
     np.testing.assert_array_equal(weights.dequantize(back), weights.dequantize(pk))
-    # 8-bit weights and sizes that are not whole blocks have no such layout
-    q8, s8 = weights.quantize_per_channel(w, 8, "f16")
-    for bad in (weights.pack(q8, s8, 8, "f16"), weights.pack(q[:40], s[:, :40], 4, "f16", 64)):
+    # 8-bit weights: their own unit order
+    q8, s8 = weights.quantize_per_channel(w, 8, "bf16")
+    pk8 = weights.pack(q8, s8, 8, "bf16")
+    pre8 = weights.preshuffle(pk8)
+    np.testing.assert_array_equal(pre8.weight.reshape(-1), port.preshuffle_int8(pk8.weight, K, N))
+    weights.save_packed(str(tmp_path / "pre8.npz"), pre8)
+    back8 = weights.load_packed(str(tmp_path / "pre8.npz"))
+    assert back8.layout == "preshuffled" and back8.b_dtype == weights.capi.I8_PRESHUFFLED
+    np.testing.assert_array_equal(weights.unshuffle(back8).weight, pk8.weight)
+    # sizes that are not whole blocks have no such layout
+    for bad in (weights.pack(q[:40], s[:, :40], 4, "f16", 64),):
         try:
             weights.preshuffle(bad)
             raise AssertionError("accepted")

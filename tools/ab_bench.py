@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--variants", default="0,4,1")
     ap.add_argument("--a", default="f16", choices=["f16", "bf16", "f8", "f8fnuz"])
     ap.add_argument("--ramp", type=int, default=1000, help="untimed launches before timing (clock settling)")
-    ap.add_argument("--b", default="i4", choices=["i4", "i4pre", "i8", "u8"], help="i4pre: packed int4 in the pre-shuffled order")
+    ap.add_argument("--b", default="i4", choices=["i4", "i4pre", "i8", "i8pre", "u8"], help="i4pre / i8pre: the weights in their pre-shuffled order")
     ap.add_argument("--group-k", type=int, default=0, help="group-wise weight scales: k per group (fp16 activations)")
     args = ap.parse_args()
     M, N, K = args.M, args.N, args.K
@@ -57,7 +57,11 @@ def main():
             b, bdt = b2, capi.I4_PRESHUFFLED
     else:
         b = torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8)
-        bdt = capi.I8 if args.b == "i8" else capi.U8_OFFSET
+        bdt = capi.I8 if args.b in ("i8", "i8pre") else capi.U8_OFFSET
+        if args.b == "i8pre":
+            b2 = torch.empty_like(b)
+            capi.preshuffle_int8(b.data_ptr(), K, K, N, b2.data_ptr(), K, torch.cuda.current_stream().cuda_stream)
+            b, bdt = b2, capi.I8_PRESHUFFLED
     c = torch.empty((M, N), dtype=adt, device=dev)
     torch.cuda.synchronize()
     sp = torch.cuda.current_stream().cuda_stream
