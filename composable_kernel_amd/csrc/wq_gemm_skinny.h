@@ -26,6 +26,31 @@
 
 namespace wq {
 
+// Where lane (column `col`, k quarter fq) of a weight stream finds its 16 bytes of the super-step that starts at k = kbeg
+// (a multiple of the super-step), and how far apart consecutive super-steps are.  Plain layouts: K runs along the
+// column, 64 bytes per super-step.  Pre-shuffled layouts (p.b_preshuf): the lane's unit of super-step i is unit
+// 4 i + fq of its column, i.e. k half fq % 2 of block 2 i + fq / 2 (packed int4: 2048 bytes per super-step) or k
+// quarter fq of block i (int8: 1024 bytes per super-step) -- a wave-wide load then reads whole 128-byte lines.
+template <int BKIND>
+__device__ __forceinline__ const uint8_t* weight_stream(const GemmParams& p, int col, int kbeg, int fq, size_t& step_bytes)
+{
+    if(p.b_preshuf)
+    {
+        if constexpr(BKIND == B_I4P)
+        {
+            step_bytes = 2048;
+            return (const uint8_t*)p.b + preshuf_unit_offset(col, (kbeg >> 5) + fq, p.ldb_bytes);
+        }
+        else
+        {
+            step_bytes = 1024;
+            return (const uint8_t*)p.b + preshuf8_unit_offset(col, (kbeg >> 4) + fq, p.ldb_bytes);
+        }
+    }
+    step_bytes = 64;
+    return (const uint8_t*)p.b + (size_t)col * p.ldb_bytes + (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
+}
+
 // NMB: 16-row blocks of activations computed (1, 2 or 4; rows beyond M are zero in LDS and never stored).
 // NB:  16-column blocks per wave (1 or 2).
 // P:   weight loads in flight per lane (4 or 1); the number of super-steps of a K slice must be a multiple of P,
@@ -69,16 +94,16 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
     {
         // ---- weight stream: the first P loads go out before anything else ----------------------------------------
         const uint8_t* bptr[NB];
+        size_t bstep = 64;
 #pragma unroll
         for(int nb = 0; nb < NB; ++nb)
-            bptr[nb] = (const uint8_t*)p.b + (size_t)(n0 + 16 * nb + fr) * p.ldb_bytes +
-                       (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
+            bptr[nb] = weight_stream<BKIND>(p, n0 + 16 * nb + fr, kz_begin, fq, bstep);
         u4_t raw[P][NB];
 #pragma unroll
         for(int i = 0; i < P; ++i)
 #pragma unroll
             for(int nb = 0; nb < NB; ++nb)
-                raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)i * 64);
+                raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)i * bstep);
 
         // ---- activation chunks: piece q = tid + 256 j of a chunk is 16 bytes of row q / CPR ------------------------
         const uint8_t* a_src[APT];
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
                     for(int nb = 0; nb < NB; ++nb)
                     {
                         w[nb]      = raw[i][nb];
-                        raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)nxt * 64);
+                        raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)nxt * bstep);
                     }
                     u4_t af[STEPS][NMB];
 #pragma unroll
@@ -231,12 +256,12 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
     const int koff   = (wave * ubase + min(wave, urem)) * (P * KS); // first k of this wave, from k_begin
     const int kbeg   = p.k_begin + koff;
 
-    const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
-                          (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
+    size_t bstep        = 64;
+    const uint8_t* bptr = weight_stream<BKIND>(p, n0 + fr, kbeg, fq, bstep);
     u4_t raw[P];
 #pragma unroll
     for(int i = 0; i < P; ++i)
-        raw[i] = *(const u4_t*)(bptr + (size_t)i * 64);
+        raw[i] = *(const u4_t*)(bptr + (size_t)i * bstep);
 
     // activations: rows 0 .. M-1 of [k_begin, k_end), row pitch klen * 2 + 16 bytes
     const int pitch = klen * 2 + 16;
@@ -264,7 +289,7 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
         {
             const u4_t w  = raw[i];
             const int nxt = min(t + i + P, nsteps - 1);
-            raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * 64);
+            raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * bstep);
             u4_t af[STEPS];
 #pragma unroll
             for(int s = 0; s < STEPS; ++s)
@@ -357,12 +382,12 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
     const int nchunks = nsteps / SPC;
     const int kbeg    = p.k_begin + (wave * ubase + min(wave, urem)) * (P * KS);
 
-    const uint8_t* bptr = (const uint8_t*)p.b + (size_t)(n0 + fr) * p.ldb_bytes +
-                          (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
+    size_t bstep        = 64;
+    const uint8_t* bptr = weight_stream<BKIND>(p, n0 + fr, kbeg, fq, bstep);
     u4_t raw[P];
 #pragma unroll
     for(int i = 0; i < P; ++i)
-        raw[i] = *(const u4_t*)(bptr + (size_t)i * 64);
+        raw[i] = *(const u4_t*)(bptr + (size_t)i * bstep);
 
     // activation chunks of this wave: piece q = lane + 64 j is 16 bytes of row q / CPR
     uint8_t* my = lds + wave * REGION;
@@ -414,7 +439,7 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
                 const int i   = cc * SPC + ii;
                 const u4_t w  = raw[i];
                 const int nxt = min(t + i + P, nsteps - 1);
-                raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * 64);
+                raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * bstep);
                 u4_t af[STEPS];
 #pragma unroll
                 for(int s = 0; s < STEPS; ++s)

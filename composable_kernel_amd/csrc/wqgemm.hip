@@ -259,7 +259,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     {
         const int ks        = is_i4(p->b_dtype) ? 128 : 64; // k per super-step of wq_gemm_skinny
         const int klen_all  = plan.k_end - plan.k_begin;
-        const bool eligible = is16(p->a_dtype) && !grouped && !preshuf && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
+        const bool eligible = is16(p->a_dtype) && !grouped && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                               p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 &&
                               klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
                               p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 &&
@@ -383,8 +383,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // for by name); there is no slow path to fall onto silently.
     if(preshuf && plan.route != ROUTE_MFMA256 && plan.route != ROUTE_F8_MFMA256 && !(p->flags & WQ_FLAG_GENERIC))
         return fail(WQ_ERR_UNSUPPORTED,
-                    "pre-shuffled B runs on the 256-tile kernels only: N %% 256 == 0, K in whole 64-k tiles (128 for fp8 "
-                    "activations), K-contiguous 16-byte aligned operands, default wave grid");
+                    "pre-shuffled B runs on the 256-tile kernels (N %% 256 == 0, K in whole 64-k tiles, 128 for fp8 "
+                    "activations, K-contiguous 16-byte aligned operands) and on the small-M kernels (M <= 64, N %% 64 == 0)");
     if(preshuf && (p->flags & (WQ_FLAG_MFMA_32X32 | WQ_FLAG_TILE_128)))
         return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled B: no 128-tile or 32x32-MFMA kernel reads this layout");
     if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)
@@ -544,6 +544,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end, gp.k_per_z = plan.k_per_z;
         gp.partial = plan.partial ? 1 : 0;
         gp.epi     = epilogue_of(p);
+        gp.b_preshuf = is_preshuf(p->b_dtype) ? 1 : 0;
         const int nmb       = p->M <= 16 ? 1 : (p->M <= 32 ? 2 : 4);
         const int ks        = is_i4(p->b_dtype) ? 128 : 64;
         // 4 loads in flight when every slice is a whole number of 4-super-step groups
@@ -562,6 +563,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.lda = p->lda, gp.ldb_bytes = is_i4(p->b_dtype) ? p->ldb / 2 : p->ldb, gp.ldc = p->ldc;
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end;
         gp.epi     = epilogue_of(p);
+        gp.b_preshuf = is_preshuf(p->b_dtype) ? 1 : 0;
         const int ks = is_i4(p->b_dtype) ? 128 : 64, klen = plan.k_end - plan.k_begin;
         // loads in flight = super-steps per unit of K dealt to a wave: as many as leave every wave at least one unit
         const int steps   = klen / ks;

@@ -257,11 +257,13 @@ def test_preshuffle_int8_host_matches_checker(port):
 
 
 def test_preshuffled_weights_routes():
-    # consumed by the 256-tile kernels, whatever M is; nothing else reads the layout and nothing falls back silently
+    # consumed by the 256-tile kernels and the small-M kernels; nothing else reads the layout and nothing falls back silently
     pre = dict(b_dtype=capi.I4_PRESHUFFLED)
     assert capi.kernel_name(_problem(**pre)) == "wq_gemm_mfma_256"
     assert "I4_PRESHUFFLED" in capi.type_string(_problem(**pre))
-    assert capi.kernel_name(_problem(M=8, **pre)) == "wq_gemm_mfma_256"        # (the small-M kernels read the packed order)
+    assert capi.kernel_name(_problem(M=8, **pre)).startswith("wq_gemm_skinny_ws")
+    assert capi.kernel_name(_problem(M=48, **pre)) == "wq_gemm_skinny"
+    assert not capi.is_supported(_problem(M=100, N=4096 + 64, **pre))          # between the two kernel families
     assert capi.kernel_name(_problem(M=512, N=512, **pre)) == "wq_gemm_mfma_256"
     assert capi.kernel_name(_problem(a_dtype=capi.BF16, **pre)) == "wq_gemm_mfma_256"
     assert capi.kernel_name(_problem(scale_group_k=128, **pre)) == "wq_gemm_mfma_256"
@@ -278,7 +280,7 @@ def test_preshuffled_weights_routes():
     pre8 = dict(b_dtype=capi.I8_PRESHUFFLED)
     assert capi.kernel_name(_problem(a_dtype=capi.BF16, N=11008, **pre8)) == "wq_gemm_mfma_256"
     assert "I8_PRESHUFFLED" in capi.type_string(_problem(**pre8))
-    assert capi.kernel_name(_problem(M=8, **pre8)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(M=8, **pre8)).startswith("wq_gemm_skinny_ws")
     assert capi.kernel_name(_problem(flags=capi.FLAG_GENERIC, **pre8)) == "wq_gemm_generic"
     assert not capi.is_supported(_problem(N=4096 + 128, **pre8))
     assert not capi.is_supported(_problem(b_layout=capi.ROW_MAJOR, **pre8))

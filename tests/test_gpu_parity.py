@@ -68,8 +68,8 @@ def test_preshuffled_weights_equal_packed_weights(port, a_dtype):
         pre = preshuffle_on_device(packed, K, N)
         want = run_fpaintb(a, packed, s, M, N, K, a_dtype=a_dtype, flags=flags | capi.FLAG_TILE_256, k_batch=kb,
                            expect_kernel=MFMA256)
-        got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, flags=flags, k_batch=kb,
-                          expect_kernel=MFMA256)
+        got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, flags=flags | (capi.FLAG_TILE_256 if M <= 64 else 0),
+                          k_batch=kb, expect_kernel=MFMA256)
         np.testing.assert_array_equal(got, want)
     # against the checker, and the general kernel on the pre-shuffled bytes (bit-exact: ascending k)
     M, N, K = 64, 256, 128
@@ -84,7 +84,7 @@ def test_preshuffled_weights_equal_packed_weights(port, a_dtype):
     else:
         exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
     np.testing.assert_array_equal(gen, exp)
-    got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, expect_kernel=MFMA256)
+    got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
     check_err(bits_to_f32(got, a_dtype), bits_to_f32(exp, a_dtype), 1e-2 if a_dtype == capi.BF16 else 1e-3, 1e-3)
     # padded K pitch (ldb = K + 64) and a K slice [128, 384) of K = 512 into an fp32 partial
     M, N, K, ldk = 256, 256, 512, 576
@@ -128,8 +128,8 @@ def test_preshuffled_int8_weights_equal_plain_int8(port, a_dtype):
         q = rng.integers(-128, 128, (N, K)).astype(np.int8)
         want = run_fpaintb(a, q, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8, flags=flags | capi.FLAG_TILE_256, k_batch=kb,
                            expect_kernel=MFMA256)
-        got = run_fpaintb(a, pre8(q, K, N, ldk), s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8_PRESHUFFLED, ldb=ldk, flags=flags,
-                          k_batch=kb, expect_kernel=MFMA256)
+        got = run_fpaintb(a, pre8(q, K, N, ldk), s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8_PRESHUFFLED, ldb=ldk,
+                          flags=flags | (capi.FLAG_TILE_256 if M <= 64 else 0), k_batch=kb, expect_kernel=MFMA256)
         np.testing.assert_array_equal(got, want)
     M, N, K = 48, 256, 128
     a = bits(rng.uniform(-1, 1, (M, K)))
@@ -142,6 +142,38 @@ def test_preshuffled_int8_weights_equal_plain_int8(port, a_dtype):
     else:
         exp = port.gemm_bf16_i8(a, q, s, M, N, K, K, 1, K, N, 0).reshape(M, N)
     np.testing.assert_array_equal(gen, exp)
+
+
+@pytest.mark.parametrize("bits4", [True, False])
+def test_preshuffled_weights_small_m_kernels(port, bits4):
+    """The small-M kernels on pre-shuffled weights (packed int4 and int8): whatever kernel the planner picks for the
+    plain layout it picks for the pre-shuffled one, and the output bits agree (same arithmetic and summation order; only
+    the addresses of the weight stream differ).  Covers the grid-split kernel with 1, 2 and 4 row blocks and with split-K,
+    and both four-waves-split-K kernels."""
+    rng = np.random.default_rng(41 + bits4)
+    for (M, N, K) in ((1, 2048, 4096), (8, 2048, 512), (16, 4096, 8192), (24, 128, 256), (40, 256, 1024), (64, 512, 4096),
+                      (5, 4096, 16384), (33, 11008 // 64 * 64, 4096)):
+        a = f16_bits(rng.uniform(-1, 1, (M, K)))
+        s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+        if bits4:
+            q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+            plain = pack_on_device(q, K, N)
+            pre, plain_dt, pre_dt = preshuffle_on_device(plain, K, N), capi.I4_PACKED, capi.I4_PRESHUFFLED
+        else:
+            q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+            plain = dev(q)
+            pre = torch.zeros(N * K, dtype=torch.int8, device="cuda")
+            capi.preshuffle_int8(plain.data_ptr(), K, K, N, pre.data_ptr(), K, torch.cuda.current_stream().cuda_stream)
+            plain_dt, pre_dt = capi.I8, capi.I8_PRESHUFFLED
+        pp = capi.fpAintB_problem(1 << 20, 1 << 20, 1 << 20, 1 << 20, M, N, K, b_dtype=plain_dt)
+        name = capi.kernel_name(pp)
+        assert name.startswith("wq_gemm_skinny")
+        want = run_fpaintb(a, plain, s, M, N, K, b_dtype=plain_dt, expect_kernel=name)
+        got = run_fpaintb(a, pre, s, M, N, K, b_dtype=pre_dt, expect_kernel=name)
+        np.testing.assert_array_equal(got, want)
+        if M * N * K <= 1 << 24:
+            exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
+            check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
 
 
 def test_preshuffled_weights_fp8_kernel(port):
@@ -1481,8 +1513,8 @@ def test_random_shapes_f8_int4_against_the_general_kernel():
 
 def test_torch_linear_preshuffled_weights(tmp_path):
     """Pre-shuffled int4 weights through the container and the torch operator: the same bits as the packed layout of
-    the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch; shapes the 256-tile
-    kernels cannot take are refused, not run slowly."""
+    the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch; shapes neither the 256-tile
+    nor the small-M kernels can take are refused, not run slowly."""
     from composable_kernel_amd import weights
     from composable_kernel_amd.torch_ops import WqLinear
     rng = np.random.default_rng(31)
@@ -1503,15 +1535,15 @@ def test_torch_linear_preshuffled_weights(tmp_path):
     assert torch.allclose(y.cpu().double(), x.cpu().double() @ wd.T, rtol=2e-3, atol=2e-3)
     # the packed layer takes the 128-tile kernel at this size (a short grid); force it onto the same kernel for the bit comparison
     from composable_kernel_amd.torch_ops import fpaintb_linear
-    for rows in (300, 5):
-        xs = x[:rows].contiguous()
-        yp = lin_pre(xs)
-        c = torch.empty((rows, N), dtype=torch.float16, device="cuda")
-        p = capi.fpAintB_problem(xs.data_ptr(), lin_pk.weight.data_ptr(), lin_pk.scale.data_ptr(), c.data_ptr(), rows, N, K,
-                                 flags=capi.FLAG_TILE_256)
-        capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        assert torch.equal(yp, c)
+    xs = x[:300].contiguous()
+    c = torch.empty((300, N), dtype=torch.float16, device="cuda")
+    p = capi.fpAintB_problem(xs.data_ptr(), lin_pk.weight.data_ptr(), lin_pk.scale.data_ptr(), c.data_ptr(), 300, N, K,
+                             flags=capi.FLAG_TILE_256)
+    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(lin_pre(xs), c)
+    # a decode-sized batch: the small-M kernel reads either layout
+    assert torch.equal(lin_pre(x[:5].contiguous()), lin_pk(x[:5].contiguous()))
     # N = 384 is not a whole number of 256-column tiles
     q2, s2 = weights.quantize_per_channel(w[:384], 4, "f16")
     lin = WqLinear(weights.preshuffle(weights.pack(q2, s2, 4, "f16")))

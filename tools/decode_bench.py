@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--b", default="i4", choices=("i4", "i8"))
+    ap.add_argument("--pre", action="store_true", help="weights in the pre-shuffled order (random bytes either way)")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008,8192x8192,28672x8192,8192x28672")
     ap.add_argument("--ms", default="1,4,16,32,64")
     ap.add_argument("--graph", action="store_true",
@@ -59,10 +60,10 @@ def main():
         copies = max(2, min(16, (320 << 20) // wbytes + 1))
         if args.b == "i4":
             ws = [torch.randint(0, 256, (N, K // 2), generator=g, device=dev, dtype=torch.uint8) for _ in range(copies)]
-            bdt = capi.I4_PACKED
+            bdt = capi.I4_PRESHUFFLED if args.pre else capi.I4_PACKED
         else:
             ws = [torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8) for _ in range(copies)]
-            bdt = capi.I8
+            bdt = capi.I8_PRESHUFFLED if args.pre else capi.I8
         s = (torch.rand((N,), generator=g, device=dev) * 0.01 + 0.001).half()
         for M in (int(v) for v in args.ms.split(",")):
             a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).half()
@@ -98,7 +99,7 @@ def main():
             run(200)
             ms = statistics.median(run(40) for _ in range(5))
             nbytes = wbytes + 2 * M * K + 2 * M * N + 2 * N
-            line = {"N": N, "K": K, "M": M, "b": args.b, "kernel": capi.kernel_name(probs[0]), "us": ms * 1e3,
+            line = {"N": N, "K": K, "M": M, "b": args.b + ("_preshuffled" if args.pre else ""), "kernel": capi.kernel_name(probs[0]), "us": ms * 1e3,
                     "algorithmic_bytes": nbytes, "hbm_gbps": nbytes / (ms * 1e-3) / 1e9,
                     "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM, "weight_copies_rotated": copies,
                     "hip_graph": bool(args.graph)}
