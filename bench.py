@@ -449,6 +449,10 @@ def run_splitk(args):
     klen = sl.length
     # each rank owns its K slice of A and of the packed weights (synthetic, per-rank seed)
     a, q, s, bp = synth_inputs(M, N, klen, 11939 + rank, dev)
+    # the rank's slice of the weights in the pre-shuffled order (as a deployment would store it; same output bits)
+    b_dtype = capi.I4_PACKED
+    if klen > 0 and klen % 64 == 0:
+        bp, b_dtype = preshuffled(bp, klen, N), capi.I4_PRESHUFFLED
     s = s.clone()
     dist.broadcast(s, src=0)  # the per-channel scales are replicated
     partial = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -459,7 +463,7 @@ def run_splitk(args):
 
     def slice_problem(a_t, s_t):
         pg = capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), partial.data_ptr(), M, N, max(klen, 64),
-                                  k_begin=0, k_end=max(klen, 64), c_dtype=capi.F32)
+                                  k_begin=0, k_end=max(klen, 64), c_dtype=capi.F32, b_dtype=b_dtype)
         assert klen == 0 or capi.is_supported(pg), capi.lib.wqgemm_last_error().decode()
         return pg
 
@@ -474,7 +478,7 @@ def run_splitk(args):
 
     def finalize(summed, out_rows, row0):
         pf = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), cur["scale"].data_ptr(), out_rows.data_ptr(),
-                                  summed.shape[0], N, max(klen, 64))
+                                  summed.shape[0], N, max(klen, 64), b_dtype=b_dtype)
         capi.reduce_finalize(pf, summed.data_ptr(), 1, sp)
 
     def step():
