@@ -124,7 +124,7 @@ def pmc_traffic(kernel):
 
 
 PEAK_8BIT_MFMA_TFLOPS = 5000.0  # dense fp8 / int8 MFMA peak of MI355X
-PMC_SUMMARIES = ("r2_mfma256_pmc.json", "r1_mfma256_pmc.json")  # newest first
+PMC_SUMMARIES = ("r2_mfma256_preshuffled_pmc.json", "r2_mfma256_pmc.json", "r1_mfma256_pmc.json")  # newest first
 
 
 def _cpu_cores():

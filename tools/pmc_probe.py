@@ -19,7 +19,7 @@ from composable_kernel_amd import capi  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--a", default="f16", choices=["f16", "bf16", "i8"])
-    ap.add_argument("--b", default="i4", choices=["i4", "i8"])
+    ap.add_argument("--b", default="i4", choices=["i4", "i4pre", "i8", "i8pre"], help="i4pre / i8pre: pre-shuffled weight order")
     ap.add_argument("--M", type=int, default=1)
     ap.add_argument("--N", type=int, default=28672)
     ap.add_argument("--K", type=int, default=8192)
@@ -41,14 +41,22 @@ def main():
         adt = torch.float16 if args.a == "f16" else torch.bfloat16
         a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).to(adt)
         s = (torch.rand((N,), generator=g, device=dev) * 2.0 ** -5 + 2.0 ** -8).to(adt)
-        if args.b == "i4":
+        if args.b in ("i4", "i4pre"):
             q = torch.randint(-8, 8, (N, K), generator=g, device=dev, dtype=torch.int8)
             b = torch.empty((N, K // 2), dtype=torch.uint8, device=dev)
             capi.pack_int4(q.data_ptr(), K, K, N, b.data_ptr(), K // 2, sp)
             bdt, bb = capi.I4_PACKED, N * K // 2
+            if args.b == "i4pre":
+                b2 = torch.empty_like(b)
+                capi.preshuffle_int4(b.data_ptr(), K // 2, K, N, b2.data_ptr(), K, sp)
+                b, bdt = b2, capi.I4_PRESHUFFLED
         else:
             b = torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8)
             bdt, bb = capi.I8, N * K
+            if args.b == "i8pre":
+                b2 = torch.empty_like(b)
+                capi.preshuffle_int8(b.data_ptr(), K, K, N, b2.data_ptr(), K, sp)
+                b, bdt = b2, capi.I8_PRESHUFFLED
         c = torch.empty((M, N), dtype=adt, device=dev)
         p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K,
                                  a_dtype=capi.F16 if args.a == "f16" else capi.BF16, b_dtype=bdt)
