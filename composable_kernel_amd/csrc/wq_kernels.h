@@ -397,6 +397,40 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
         b_src[i]        = (const uint8_t*)p.b + (size_t)min(n0 + col, p.N - 1) * p.ldb_bytes +
                    (size_t)kz_begin / 8 * BInfo<BKIND>::kBytesPer8K + chunk * 16;
     }
+    // Pre-shuffled weights (p.b_preshuf): every DMA piece is one contiguous KiB of global memory, K tile after K tile.
+    // Packed int4: piece = 32 columns, stored in the order of its own LDS image (unit (column 16 t + r, k half h) at
+    // slot 32 t + 16 h + r), so lane l copies slot l and only the fragment reads below change their addresses.  int8:
+    // piece = 16 columns, units column after column; the lane that fills slot l fetches the unit the swizzled image
+    // wants there, and the reads do not change.  Pieces past N in a partial last column tile re-read the last block.
+    size_t b_tile_stride = T::B_ROW_BYTES;
+    if(p.b_preshuf)
+    {
+        b_tile_stride = 1024;
+#pragma unroll
+        for(int i = 0; i < B_INSTR; ++i)
+        {
+            if constexpr(BKIND == B_I4P)
+                b_src[i] = (const uint8_t*)p.b + (size_t)min((n0 >> 5) + wave, (p.N >> 5) - 1) * ((size_t)p.ldb_bytes * 32) +
+                           (size_t)(kz_begin >> 6) * 1024 + lane * 16;
+            else
+            {
+                const int c = lane >> 2, j = (lane & 3) ^ ((c >> 2) & 3);
+                b_src[i]    = (const uint8_t*)p.b +
+                           (size_t)min((n0 >> 4) + wave * B_INSTR + i, (p.N >> 4) - 1) * ((size_t)p.ldb_bytes * 16) +
+                           (size_t)(kz_begin >> 6) * 1024 + (c * 4 + j) * 16;
+            }
+        }
+    }
+    // packed int4: byte offset inside the B image of this lane's word of k-step s of column block nt = 0 of its wave
+    // (further column blocks: + 512 nt in both layouts)
+    int raw_off[2] = {0, 0};
+    if constexpr(BKIND == B_I4P)
+    {
+#pragma unroll
+        for(int s = 0; s < 2; ++s)
+            raw_off[s] = p.b_preshuf ? wn * 2048 + (s * 16 + fr) * 16 + fq * 4
+                                     : (wn * 64 + fr) * 32 + ((s ^ ((fr >> 2) & 1)) << 4) + fq * 4;
+    }
 
     auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         uint8_t* sa = lds + buf * T::STAGE;
@@ -406,7 +440,7 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
             glds16(a_src[i] + (size_t)kt * T::A_ROW_BYTES, sa + (wave * 4 + i) * 1024);
 #pragma unroll
         for(int i = 0; i < B_INSTR; ++i)
-            glds16(b_src[i] + (size_t)kt * T::B_ROW_BYTES, sb + (wave * B_INSTR + i) * 1024);
+            glds16(b_src[i] + (size_t)kt * b_tile_stride, sb + (wave * B_INSTR + i) * 1024);
     };
 
     f4_t acc[4][4]; // [nt][mt]
@@ -426,11 +460,10 @@ __global__ __launch_bounds__(256) void wq_gemm_mfma_128(const GemmParams p)
 #pragma unroll
             for(int nt = 0; nt < 4; ++nt)
             {
-                const int col = wn * 64 + nt * 16 + fr;
+                [[maybe_unused]] const int col = wn * 64 + nt * 16 + fr;
                 if constexpr(BKIND == B_I4P)
                 {
-                    const int chunk  = s ^ ((col >> 2) & 1);
-                    const uint32_t w = *(const uint32_t*)(sb + col * 32 + chunk * 16 + fq * 4);
+                    const uint32_t w = *(const uint32_t*)(sb + raw_off[s] + nt * 512);
                     wf[nt]           = dequant8(sc[nt], w, std::integral_constant<int, B_I4P>{});
                 }
                 else

@@ -351,8 +351,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     {
         // 256 x 256 tiles, one workgroup per CU: worth it once the grid covers at least half the chip
         const long wgs = (long)((p->M + 255) / 256) * (p->N / 256) * plan.k_batch;
-        // (pre-shuffled weights exist for this kernel family only: short grids run it too)
-        if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256) || preshuf)
+        if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256))
             plan.route = ROUTE_MFMA256;
     }
     // Few tiles (a short M against a narrow N) leave most CUs idle: split K across blockIdx.z when the caller has not,
@@ -379,14 +378,14 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
             }
         }
     }
-    // Pre-shuffled weights are laid out for the 256-tile kernels (and readable by the general kernel when it is asked
+    // Pre-shuffled weights are read by the tile kernels and the small-M kernels (and by the general kernel when it is asked
     // for by name); there is no slow path to fall onto silently.
-    if(preshuf && plan.route != ROUTE_MFMA256 && plan.route != ROUTE_F8_MFMA256 && !(p->flags & WQ_FLAG_GENERIC))
+    if(preshuf && plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC))
         return fail(WQ_ERR_UNSUPPORTED,
-                    "pre-shuffled B runs on the 256-tile kernels (N %% 256 == 0, K in whole 64-k tiles, 128 for fp8 "
-                    "activations, K-contiguous 16-byte aligned operands) and on the small-M kernels (M <= 64, N %% 64 == 0)");
-    if(preshuf && (p->flags & (WQ_FLAG_MFMA_32X32 | WQ_FLAG_TILE_128)))
-        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled B: no 128-tile or 32x32-MFMA kernel reads this layout");
+                    "pre-shuffled B runs on the matrix-core kernels only: K-contiguous 16-byte aligned operands, K in whole "
+                    "64-k tiles (128 for fp8 activations, which also need N %% 256 == 0), scale groups of a multiple of 64 k");
+    if(preshuf && (p->flags & WQ_FLAG_MFMA_32X32))
+        return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled B: the 32x32-MFMA kernel does not read this layout");
     if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)
         return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs N to be a multiple of 256 and tile-aligned operands");
     if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_MFMA128)

@@ -21,8 +21,8 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
                    bias: torch.Tensor | None, layout: str = "packed") -> torch.Tensor:
     """y[m, n] = epilogue( sum_k x[m, k] * dequant(weight[n, k], scale[n]) [, bias[n]] ).
 
-    layout = "preshuffled": the weight bytes are in the order of wqgemm_preshuffle_int4 / _int8; runs on the 256-tile
-    kernels only (N a multiple of 256, K of 64) and raises where they cannot take the problem.
+    layout = "preshuffled": the weight bytes are in the order of wqgemm_preshuffle_int4 / _int8; needs N a multiple of 32
+    and K of 64, and raises where no matrix-core kernel can take the problem.
 
     x (M, K) fp16 / bf16, row-major; weight uint8 (N, K/2) packed int4 (bits = 4) or int8 (N, K) (bits = 8);
     scale and bias (N,) of x's dtype; epilogue in {"none", "fastgelu", "add", "add_fastgelu"}.

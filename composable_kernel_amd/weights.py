@@ -15,8 +15,8 @@ collapsed, in the (K / block, N) shape of example/65_gemm_multiply_multiply/gemm
 Weights can additionally be stored pre-shuffled (``preshuffle``; ``WQ_I4_PRESHUFFLED`` / ``WQ_I8_PRESHUFFLED``, the layouts
 documented at ``wqgemm_preshuffle_int4`` / ``wqgemm_preshuffle_int8``): the same bytes with their 16-byte units (32 or 16
 consecutive k of one column) in the order the
-256-tile kernels fetch them, so that every wave-wide weight fetch is one contiguous kilobyte.  Such weights run on those
-kernels only (N a multiple of 256, K of 64).
+tile kernels fetch them, so that every wave-wide weight fetch is whole 128-byte lines.  Needs N a multiple of 32 and K
+of 64; every matrix-core kernel reads it.
 
 Container (``save_packed`` / ``load_packed``): a NumPy ``.npz`` archive with the arrays ``weight`` (uint8 or int8,
 shape (N, K/2) or (N, K); for the pre-shuffled layout the N * K / 2 bytes keep the (N, K/2) shape although rows no longer

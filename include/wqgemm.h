@@ -39,7 +39,7 @@ typedef enum wq_dtype
     WQ_I4_PACKED = 6, /* two offset-binary nibbles per byte, layout documented at wqgemm_pack_int4   */
     WQ_I32       = 7,
     WQ_F8_E4M3FN = 8, /* OCP E4M3 ("e4m3fn") bytes, bias 7, 0x7F/0xFF = NaN: the fp8 the gfx950 matrix core decodes; no counterpart in the reference, whose f8_t is FNUZ only */
-    WQ_I4_PRESHUFFLED = 9, /* WQ_I4_PACKED's nibbles with its 16-byte units (32 consecutive k of one column) stored in the order the 256-tile kernels consume them; layout documented at wqgemm_preshuffle_int4 */
+    WQ_I4_PRESHUFFLED = 9, /* WQ_I4_PACKED's nibbles with its 16-byte units (32 consecutive k of one column) stored in the order the matrix-core kernels fetch them; layout documented at wqgemm_preshuffle_int4 */
     WQ_I8_PRESHUFFLED = 10 /* WQ_I8 bytes with their 16-byte units (16 consecutive k of one column) in that order; layout documented at wqgemm_preshuffle_int8 */
 } wq_dtype;
 
@@ -236,8 +236,8 @@ int wqgemm_pack_int4(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t
 int wqgemm_pack_int4_host(const int8_t* q, int32_t ldq, int32_t K, int32_t N, uint8_t* out,
                           int32_t ld_bytes);
 
-/* Re-order WQ_I4_PACKED weights (column n at packed + n*ld_bytes) into WQ_I4_PRESHUFFLED, the offline layout whose
- * every wave-wide weight fetch of the 256-tile kernels is one contiguous kilobyte (the role of the pre-shuffled B of
+/* Re-order WQ_I4_PACKED weights (column n at packed + n*ld_bytes) into WQ_I4_PRESHUFFLED, the offline layout in
+ * which every wave-wide weight fetch of the tile kernels is one contiguous kilobyte (the role of the pre-shuffled B of
  * example/65_gemm_multiply_multiply's newer drivers; the reference tree here has no int4 form of it).  The unit that
  * moves is 16 bytes = the 32 consecutive k [32j, 32j+32) of one column, nibble order inside it as in WQ_I4_PACKED.
  * Block (cb, kb) = columns [32cb, 32cb+32) x k [64kb, 64kb+64) = 64 units = 1024 bytes at

@@ -257,32 +257,36 @@ def test_preshuffle_int8_host_matches_checker(port):
 
 
 def test_preshuffled_weights_routes():
-    # consumed by the 256-tile kernels and the small-M kernels; nothing else reads the layout and nothing falls back silently
+    # read by every matrix-core kernel family; nothing falls back silently onto the general kernel
     pre = dict(b_dtype=capi.I4_PRESHUFFLED)
     assert capi.kernel_name(_problem(**pre)) == "wq_gemm_mfma_256"
     assert "I4_PRESHUFFLED" in capi.type_string(_problem(**pre))
     assert capi.kernel_name(_problem(M=8, **pre)).startswith("wq_gemm_skinny_ws")
     assert capi.kernel_name(_problem(M=48, **pre)) == "wq_gemm_skinny"
-    assert not capi.is_supported(_problem(M=100, N=4096 + 64, **pre))          # between the two kernel families
-    assert capi.kernel_name(_problem(M=512, N=512, **pre)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(M=512, N=512, **pre)) == "wq_gemm_mfma_128"     # a short grid, as for the plain order
+    assert capi.kernel_name(_problem(N=4096 + 128, **pre)) == "wq_gemm_mfma_128"     # N % 256 != 0
+    assert capi.kernel_name(_problem(M=100, N=4096 + 32, **pre)) == "wq_gemm_mfma_128"
+    assert capi.kernel_name(_problem(flags=capi.FLAG_TILE_128, **pre)) == "wq_gemm_mfma_128"
     assert capi.kernel_name(_problem(a_dtype=capi.BF16, **pre)) == "wq_gemm_mfma_256"
     assert capi.kernel_name(_problem(scale_group_k=128, **pre)) == "wq_gemm_mfma_256"
     assert capi.kernel_name(_problem(flags=capi.FLAG_GENERIC, **pre)) == "wq_gemm_generic"
-    assert not capi.is_supported(_problem(N=4096 + 128, **pre))                 # N % 256 != 0: no kernel
-    assert b"256-tile" in capi.lib.wqgemm_last_error()
     assert not capi.is_supported(_problem(N=4096 + 16, **pre))                  # N % 32 != 0: not even a layout
     assert not capi.is_supported(_problem(K=4096 + 32, ldb=4096 + 64, **pre))   # K % 64 != 0
     assert not capi.is_supported(_problem(ldb=4096 + 32, **pre))                # K pitch must be whole 64-k blocks
     assert capi.is_supported(_problem(ldb=4096 + 64, **pre))
-    assert not capi.is_supported(_problem(flags=capi.FLAG_TILE_128, **pre))
     assert not capi.is_supported(_problem(scale_group_k=32, **pre))             # groups the tile kernels cannot take
+    assert b"matrix-core" in capi.lib.wqgemm_last_error()
+    # fp8 activations: the 256-tile kernel or nothing
+    f8 = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, scale=None, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=0x10000, d1=0x10000)
+    assert capi.kernel_name(_problem(**f8, **pre)) == "wq_gemm_f8_mfma_256"
+    assert not capi.is_supported(_problem(N=4096 + 128, **f8, **pre))
     # 8-bit weights in their pre-shuffled order: the same rules; not an operand of the int8 x int8 requantised GEMM
     pre8 = dict(b_dtype=capi.I8_PRESHUFFLED)
     assert capi.kernel_name(_problem(a_dtype=capi.BF16, N=11008, **pre8)) == "wq_gemm_mfma_256"
     assert "I8_PRESHUFFLED" in capi.type_string(_problem(**pre8))
     assert capi.kernel_name(_problem(M=8, **pre8)).startswith("wq_gemm_skinny_ws")
+    assert capi.kernel_name(_problem(N=4096 + 128, **pre8)) == "wq_gemm_mfma_128"
     assert capi.kernel_name(_problem(flags=capi.FLAG_GENERIC, **pre8)) == "wq_gemm_generic"
-    assert not capi.is_supported(_problem(N=4096 + 128, **pre8))
     assert not capi.is_supported(_problem(b_layout=capi.ROW_MAJOR, **pre8))
     assert not capi.is_supported(_problem(a_dtype=capi.I8, c_dtype=capi.I8, scale=None, epilogue=capi.EPI_ACT_MUL_CLAMP,
                                           requant=0.03, **pre8))

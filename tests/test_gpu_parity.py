@@ -68,7 +68,7 @@ def test_preshuffled_weights_equal_packed_weights(port, a_dtype):
         pre = preshuffle_on_device(packed, K, N)
         want = run_fpaintb(a, packed, s, M, N, K, a_dtype=a_dtype, flags=flags | capi.FLAG_TILE_256, k_batch=kb,
                            expect_kernel=MFMA256)
-        got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, flags=flags | (capi.FLAG_TILE_256 if M <= 64 else 0),
+        got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, flags=flags | capi.FLAG_TILE_256,
                           k_batch=kb, expect_kernel=MFMA256)
         np.testing.assert_array_equal(got, want)
     # against the checker, and the general kernel on the pre-shuffled bytes (bit-exact: ascending k)
@@ -93,13 +93,13 @@ def test_preshuffled_weights_equal_packed_weights(port, a_dtype):
     packed = pack_on_device(q, K, N)
     pre = preshuffle_on_device(packed, K, N, ldk)
     want = run_fpaintb(a, packed, s, M, N, K, a_dtype=a_dtype, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
-    got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, ldb=ldk, expect_kernel=MFMA256)
+    got = run_fpaintb(a, pre, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I4_PRESHUFFLED, ldb=ldk, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
     np.testing.assert_array_equal(got, want)
     if a_dtype == capi.F16:
         # group-wise scales (groups of 128 k)
         sg = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, (K // 128, N)))
         want = run_fpaintb(a, packed, sg, M, N, K, flags=capi.FLAG_TILE_256, scale_group_k=128, expect_kernel=MFMA256)
-        got = run_fpaintb(a, pre, sg, M, N, K, b_dtype=capi.I4_PRESHUFFLED, ldb=ldk, scale_group_k=128, expect_kernel=MFMA256)
+        got = run_fpaintb(a, pre, sg, M, N, K, b_dtype=capi.I4_PRESHUFFLED, ldb=ldk, scale_group_k=128, flags=capi.FLAG_TILE_256, expect_kernel=MFMA256)
         np.testing.assert_array_equal(got, want)
 
 
@@ -129,7 +129,7 @@ def test_preshuffled_int8_weights_equal_plain_int8(port, a_dtype):
         want = run_fpaintb(a, q, s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8, flags=flags | capi.FLAG_TILE_256, k_batch=kb,
                            expect_kernel=MFMA256)
         got = run_fpaintb(a, pre8(q, K, N, ldk), s, M, N, K, a_dtype=a_dtype, b_dtype=capi.I8_PRESHUFFLED, ldb=ldk,
-                          flags=flags | (capi.FLAG_TILE_256 if M <= 64 else 0), k_batch=kb, expect_kernel=MFMA256)
+                          flags=flags | capi.FLAG_TILE_256, k_batch=kb, expect_kernel=MFMA256)
         np.testing.assert_array_equal(got, want)
     M, N, K = 48, 256, 128
     a = bits(rng.uniform(-1, 1, (M, K)))
@@ -174,6 +174,42 @@ def test_preshuffled_weights_small_m_kernels(port, bits4):
         if M * N * K <= 1 << 24:
             exp = port.fpAintB_gemm_f16(a, q, s, M, N, K, K, K, N).reshape(M, N)
             check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("bits4", [True, False])
+def test_preshuffled_weights_128_tile_kernel(port, bits4):
+    """The 128-tile kernel on pre-shuffled weights: bit-equal to the plain layout (random data) for whole tiles, partial
+    last row and column tiles (N a multiple of 32 only), bf16, planner-chosen split-K with a workspace, a K slice and
+    group-wise scales."""
+    rng = np.random.default_rng(43 + bits4)
+    for (M, N, K, a_dtype, kb, gk) in ((128, 128, 128, capi.F16, 1, 0), (200, 160, 192, capi.F16, 1, 0), (256, 96, 256, capi.BF16, 1, 0),
+                                       (512, 512, 2048, capi.F16, 1, 0), (128, 384, 512, capi.BF16, 2, 0), (130, 224, 256, capi.F16, 1, 64)):
+        bits = f16_bits if a_dtype == capi.F16 else bf16_bits
+        a = bits(rng.uniform(-1, 1, (M, K)))
+        s = bits(rng.uniform(2.0 ** -8, 2.0 ** -4, (K // gk, N) if gk else N))
+        if bits4:
+            q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+            plain = pack_on_device(q, K, N)
+            pre, plain_dt, pre_dt = preshuffle_on_device(plain, K, N), capi.I4_PACKED, capi.I4_PRESHUFFLED
+        else:
+            q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+            plain = dev(q)
+            pre = torch.zeros(N * K, dtype=torch.int8, device="cuda")
+            capi.preshuffle_int8(plain.data_ptr(), K, K, N, pre.data_ptr(), K, torch.cuda.current_stream().cuda_stream)
+            plain_dt, pre_dt = capi.I8, capi.I8_PRESHUFFLED
+        kw = dict(a_dtype=a_dtype, flags=capi.FLAG_TILE_128, k_batch=kb, scale_group_k=gk, expect_kernel=MFMA)
+        want = run_fpaintb(a, plain, s, M, N, K, b_dtype=plain_dt, **kw)
+        got = run_fpaintb(a, pre, s, M, N, K, b_dtype=pre_dt, **kw)
+        np.testing.assert_array_equal(got, want)
+    # default routing of a mid-sized problem: the same kernel and planner split for both layouts
+    M, N, K = 512, 1024, 4096
+    a = f16_bits(rng.uniform(-1, 1, (M, K)))
+    s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    plain = pack_on_device(q, K, N)
+    want = run_fpaintb(a, plain, s, M, N, K, expect_kernel=MFMA)
+    got = run_fpaintb(a, preshuffle_on_device(plain, K, N), s, M, N, K, b_dtype=capi.I4_PRESHUFFLED, expect_kernel=MFMA)
+    np.testing.assert_array_equal(got, want)
 
 
 def test_preshuffled_weights_fp8_kernel(port):
@@ -1513,8 +1549,8 @@ def test_random_shapes_f8_int4_against_the_general_kernel():
 
 def test_torch_linear_preshuffled_weights(tmp_path):
     """Pre-shuffled int4 weights through the container and the torch operator: the same bits as the packed layout of
-    the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch; shapes neither the 256-tile
-    nor the small-M kernels can take are refused, not run slowly."""
+    the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch and for an N that only the
+    128-tile kernel takes."""
     from composable_kernel_amd import weights
     from composable_kernel_amd.torch_ops import WqLinear
     rng = np.random.default_rng(31)
@@ -1533,22 +1569,14 @@ def test_torch_linear_preshuffled_weights(tmp_path):
     y = lin_pre(x)
     wd = torch.from_numpy(weights.dequantize(pk)).double()
     assert torch.allclose(y.cpu().double(), x.cpu().double() @ wd.T, rtol=2e-3, atol=2e-3)
-    # the packed layer takes the 128-tile kernel at this size (a short grid); force it onto the same kernel for the bit comparison
+    # the planner treats both layouts alike (same kernel, same split): equal bits for a prefill-sized and a decode-sized batch
     from composable_kernel_amd.torch_ops import fpaintb_linear
-    xs = x[:300].contiguous()
-    c = torch.empty((300, N), dtype=torch.float16, device="cuda")
-    p = capi.fpAintB_problem(xs.data_ptr(), lin_pk.weight.data_ptr(), lin_pk.scale.data_ptr(), c.data_ptr(), 300, N, K,
-                             flags=capi.FLAG_TILE_256)
-    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert torch.equal(lin_pre(xs), c)
-    # a decode-sized batch: the small-M kernel reads either layout
-    assert torch.equal(lin_pre(x[:5].contiguous()), lin_pk(x[:5].contiguous()))
-    # N = 384 is not a whole number of 256-column tiles
+    for rows in (300, 5):
+        assert torch.equal(lin_pre(x[:rows].contiguous()), lin_pk(x[:rows].contiguous()))
+    # N = 384 is not a whole number of 256-column tiles: the 128-tile kernel reads the layout too
     q2, s2 = weights.quantize_per_channel(w[:384], 4, "f16")
-    lin = WqLinear(weights.preshuffle(weights.pack(q2, s2, 4, "f16")))
-    with pytest.raises((ValueError, RuntimeError)):
-        lin(x)
+    pk2 = weights.pack(q2, s2, 4, "f16")
+    assert torch.equal(WqLinear(weights.preshuffle(pk2))(x), WqLinear(pk2)(x))
     with pytest.raises(ValueError):
         fpaintb_linear(x, lin_pre.weight, lin_pre.scale, 4, "none", None, "shuffled")
     # 8-bit weights, bf16 activations
