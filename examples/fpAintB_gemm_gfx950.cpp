@@ -3,8 +3,9 @@
 // verification flow as Composable Kernel's example/64_fpAintB_gemm (run_gemm_example.inc:6-172,
 // common.hpp:85-123), with the weights drawn from the int4 range and packed two per byte.
 //
-//   example_fpAintB_gemm_gfx950 [verify init time_kernel [M N K StrideA StrideB StrideC]]
+//   example_fpAintB_gemm_gfx950 [verify init time_kernel [M N K StrideA StrideB StrideC [preshuffle]]]
 //     init: 0 none, 1 integer values, 2 decimal values
+//     preshuffle: 1 = store the packed weights in the engine's pre-shuffled order first (same results, faster fetches)
 #include <iostream>
 
 #include "ck/ck.hpp"
@@ -23,29 +24,38 @@ using PassThrough = ck::tensor_operation::element_wise::PassThrough;
 
 using ADataType     = ck::half_t;
 using QuantDataType = int8_t;          // host-side weights, values -8..7
-using BDataType     = ck::wq_int4x2_t; // device-side packed weights
 using ScaleDataType = ck::half_t;
 using CDataType     = ck::half_t;
 
-using DeviceGemmInstance =
-    ck::tensor_operation::device::DeviceFpAintBGemm_Mfma_gfx950<Row, Col, Row, ADataType, BDataType, ScaleDataType,
+using DeviceGemmInstance = // device-side weights: packed two per byte
+    ck::tensor_operation::device::DeviceFpAintBGemm_Mfma_gfx950<Row, Col, Row, ADataType, ck::wq_int4x2_t, ScaleDataType,
                                                                 CDataType, PassThrough, PassThrough, PassThrough>;
+using DeviceGemmInstancePreshuffled =
+    ck::tensor_operation::device::DeviceFpAintBGemm_Mfma_gfx950<Row, Col, Row, ADataType, ck::wq_int4x2_preshuffled_t,
+                                                                ScaleDataType, CDataType, PassThrough, PassThrough, PassThrough>;
 using ReferenceGemmInstance =
     ck::tensor_operation::host::ReferencefpAintBGemm<ADataType, QuantDataType, ScaleDataType, CDataType, float,
                                                      PassThrough, PassThrough, PassThrough>;
+
+template <typename DeviceGemmInstance, bool Preshuffle>
+int run(bool do_verification, int init_method, bool time_kernel, ck::index_t M, ck::index_t N, ck::index_t K, ck::index_t StrideA,
+        ck::index_t StrideB, ck::index_t StrideC);
 
 int main(int argc, char* argv[])
 {
     bool do_verification = true;
     int init_method      = 1;
     bool time_kernel     = false;
+    bool preshuffle      = false;
     ck::index_t M = 3840, N = 4096, K = 4096, StrideA = 4096, StrideB = 4096, StrideC = 4096;
-    if(argc == 4 || argc == 10)
+    if(argc == 4 || argc == 10 || argc == 11)
     {
         do_verification = std::stoi(argv[1]);
         init_method     = std::stoi(argv[2]);
         time_kernel     = std::stoi(argv[3]);
-        if(argc == 10)
+        if(argc == 11)
+            preshuffle = std::stoi(argv[10]) != 0;
+        if(argc >= 10)
         {
             M = std::stoi(argv[4]), N = std::stoi(argv[5]), K = std::stoi(argv[6]);
             StrideA = std::stoi(argv[7]), StrideB = std::stoi(argv[8]), StrideC = std::stoi(argv[9]);
@@ -54,10 +64,19 @@ int main(int argc, char* argv[])
     else if(argc != 1)
     {
         std::cerr << "arg1: verification (0=no, 1=yes)\narg2: initialization (0=no init, 1=integer value, "
-                     "2=decimal value)\narg3: time kernel (0=no, 1=yes)\narg4 to 9: M, N, K, StrideA, StrideB, StrideC\n";
+                     "2=decimal value)\narg3: time kernel (0=no, 1=yes)\narg4 to 9: M, N, K, StrideA, StrideB, StrideC\n"
+                     "arg10: 1 = pre-shuffled weight order\n";
         return 1;
     }
+    return preshuffle ? run<DeviceGemmInstancePreshuffled, true>(do_verification, init_method, time_kernel, M, N, K, StrideA, StrideB, StrideC)
+                      : run<DeviceGemmInstance, false>(do_verification, init_method, time_kernel, M, N, K, StrideA, StrideB, StrideC);
+}
 
+template <typename DeviceGemmInstance, bool Preshuffle>
+int run(bool do_verification, int init_method, bool time_kernel, ck::index_t M, ck::index_t N, ck::index_t K, ck::index_t StrideA,
+        ck::index_t StrideB, ck::index_t StrideC)
+{
+    using BDataType = std::conditional_t<Preshuffle, ck::wq_int4x2_preshuffled_t, ck::wq_int4x2_t>;
     const auto m = static_cast<std::size_t>(M), n = static_cast<std::size_t>(N), k = static_cast<std::size_t>(K);
     Tensor<ADataType> a_m_k(HostTensorDescriptor({m, k}, {static_cast<std::size_t>(StrideA), 1}));
     Tensor<QuantDataType> quant_b_k_n(HostTensorDescriptor({k, n}, {1, static_cast<std::size_t>(StrideB)}));
@@ -87,6 +106,17 @@ int main(int argc, char* argv[])
     {
         std::cerr << wqgemm_last_error() << std::endl;
         return 1;
+    }
+    if constexpr(Preshuffle)
+    {
+        // offline step of a deployment: the same bytes in the order the kernels fetch them (K pitch = StrideB)
+        std::vector<uint8_t> pre(b_packed.size());
+        if(wqgemm_preshuffle_int4_host(b_packed.data(), static_cast<int>(packed_ld), K, N, pre.data(), StrideB) != WQ_OK)
+        {
+            std::cerr << wqgemm_last_error() << std::endl;
+            return 1;
+        }
+        b_packed.swap(pre);
     }
 
     DeviceMem a_buf(sizeof(ADataType) * a_m_k.mDesc.GetElementSpaceSize());

@@ -65,6 +65,16 @@ struct wq_int4x2_t
 {
     uint8_t data;
 };
+// The same nibbles, and plain int8 weights, in their pre-shuffled order (wqgemm_preshuffle_int4 / _int8 in
+// include/wqgemm.h): written once offline; StrideB is the K pitch handed to the re-layout.
+struct wq_int4x2_preshuffled_t
+{
+    uint8_t data;
+};
+struct wq_int8_preshuffled_t
+{
+    int8_t data;
+};
 
 namespace tensor_operation {
 namespace device {
@@ -112,6 +122,16 @@ template <>
 struct dtype_of<ck::wq_int4x2_t>
 {
     static constexpr int value = WQ_I4_PACKED;
+};
+template <>
+struct dtype_of<ck::wq_int4x2_preshuffled_t>
+{
+    static constexpr int value = WQ_I4_PRESHUFFLED;
+};
+template <>
+struct dtype_of<ck::wq_int8_preshuffled_t>
+{
+    static constexpr int value = WQ_I8_PRESHUFFLED;
 };
 template <>
 struct dtype_of<int32_t>
@@ -318,7 +338,11 @@ struct DeviceFpAintBGemm_Mfma_gfx950
         p.b_dtype = wq_detail::dtype_of<BDataType>::value;
         p.c_dtype = wq_detail::dtype_of<CDataType>::value;
         return std::string("DeviceFpAintBGemm_Mfma_gfx950<") + (p.a_dtype == WQ_BF16 ? "BF16" : "F16") + ", " +
-               (p.b_dtype == WQ_I4_PACKED ? "I4x2" : (p.b_dtype == WQ_I8 ? "I8" : "U8")) +
+               (p.b_dtype == WQ_I4_PACKED        ? "I4x2"
+                : p.b_dtype == WQ_I4_PRESHUFFLED ? "I4_PRESHUFFLED"
+                : p.b_dtype == WQ_I8_PRESHUFFLED ? "I8_PRESHUFFLED"
+                : p.b_dtype == WQ_I8             ? "I8"
+                                                 : "U8") +
                ", LdsDma, DequantInRegister, Mfma16x16x32>";
     }
 };

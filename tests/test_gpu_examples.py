@@ -33,6 +33,15 @@ def test_fpAintB_example_standalone(init):
     assert "DeviceFpAintBGemm_Mfma_gfx950" in r.stdout
 
 
+@pytest.mark.parametrize("shape", [(256, 384, 512, 512, 512, 384), (1024, 512, 1024, 1024, 1088, 512), (24, 256, 512, 512, 512, 256)])
+def test_fpAintB_example_preshuffled_weights(shape):
+    """The same driver with the weights stored in the pre-shuffled order (host re-layout, facade type tag
+    ck::wq_int4x2_preshuffled_t): 128-tile, 256-tile (padded K pitch) and small-M kernels, CK's host reference + check_err."""
+    r = _run(os.path.join(EX, "example_fpAintB_gemm_gfx950"), 1, 2, 1, *shape, 1)
+    assert r.returncode == 0 and "verification: PASS" in r.stdout
+    assert "I4_PRESHUFFLED" in r.stdout
+
+
 def test_fpAintB_example_ragged_shape_uses_generic_kernel():
     r = _run(os.path.join(EX, "example_fpAintB_gemm_gfx950"), 1, 2, 0, 100, 72, 200, 200, 200, 72)
     assert r.returncode == 0 and "verification: PASS" in r.stdout
