@@ -51,14 +51,24 @@ __device__ __forceinline__ const uint8_t* weight_stream(const GemmParams& p, int
     return (const uint8_t*)p.b + (size_t)col * p.ldb_bytes + (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
 }
 
+// Group-wise scales in the small-M kernels (GROUPED instances; fp16 activations, groups of a power of two of at least the
+// 32 (packed int4) or 16 (int8) k a lane takes from one super-step, so that a lane's weights of a super-step share one
+// scale): the scale of (column, super-step) travels with that super-step's weights -- fetched P super-steps ahead from
+// the (L2-resident) scale rows and installed right before the dequantisation.
+__device__ __forceinline__ uint16_t group_scale(const GemmParams& p, const uint16_t* col_scale, int k)
+{
+    return col_scale[(size_t)(k >> p.scale_group_shift) * p.ld_scale];
+}
+
 // NMB: 16-row blocks of activations computed (1, 2 or 4; rows beyond M are zero in LDS and never stored).
 // NB:  16-column blocks per wave (1 or 2).
 // P:   weight loads in flight per lane (4 or 1); the number of super-steps of a K slice must be a multiple of P,
 //      which keeps the loop body free of data-dependent branches (so the compiler's wait counts leave P - 1 loads
 //      in flight).  The planner picks slices that allow P = 4; P = 1 serves everything else.
-template <int AK, int BKIND, int NMB, int P, int NB>
+template <int AK, int BKIND, int NMB, int P, int NB, bool GROUPED = false>
 __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 {
+    static_assert(!GROUPED || AK == A_F16, "group-wise scales: fp16 activations");
     constexpr int CH     = BKIND == B_I4P ? 32 : 16; // k per lane per super-step (16 bytes of weights)
     constexpr int KS     = 4 * CH;                   // k per super-step
     constexpr int STEPS  = CH / 8;                   // MFMA k-steps per super-step
@@ -104,6 +114,19 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 #pragma unroll
             for(int nb = 0; nb < NB; ++nb)
                 raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)i * bstep);
+        const uint16_t* sptr[NB]; // GROUPED: scale column of this lane's weight column
+        uint16_t sraw[P][NB];
+        if constexpr(GROUPED)
+        {
+#pragma unroll
+            for(int nb = 0; nb < NB; ++nb)
+                sptr[nb] = (const uint16_t*)p.scale + n0 + 16 * nb + fr;
+#pragma unroll
+            for(int i = 0; i < P; ++i)
+#pragma unroll
+                for(int nb = 0; nb < NB; ++nb)
+                    sraw[i][nb] = group_scale(p, sptr[nb], kz_begin + i * KS + fq * CH);
+        }
 
         // ---- activation chunks: piece q = tid + 256 j of a chunk is 16 bytes of row q / CPR ------------------------
         const uint8_t* a_src[APT];
@@ -133,7 +156,8 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
         ScaleReg<AK> sc[NB];
 #pragma unroll
         for(int nb = 0; nb < NB; ++nb)
-            sc[nb].set(p.scale ? ((const uint16_t*)p.scale)[n0 + 16 * nb + fr] : unit_scale_bits<AK>());
+            sc[nb].set(GROUPED ? unit_scale_bits<AK>()
+                               : (p.scale ? ((const uint16_t*)p.scale)[n0 + 16 * nb + fr] : unit_scale_bits<AK>()));
 
         const uint8_t* a_lane = lds + fr * PITCH + fq * CH * 2;
         for(int t = 0; t < nsteps; t += P)
@@ -162,6 +186,11 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
                     {
                         w[nb]      = raw[i][nb];
                         raw[i][nb] = *(const u4_t*)(bptr[nb] + (size_t)nxt * bstep);
+                        if constexpr(GROUPED)
+                        {
+                            sc[nb].set(sraw[i][nb]);
+                            sraw[i][nb] = group_scale(p, sptr[nb], kz_begin + nxt * KS + fq * CH);
+                        }
                     }
                     u4_t af[STEPS][NMB];
 #pragma unroll
@@ -233,9 +262,10 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 // the epilogue.  grid (N / 16), 256 threads.  Only the M real rows of the activations are staged (lanes of the
 // zero rows read nothing), so M = 1 costs 2 K bytes of LDS; the image must fit (the planner uses this variant up to
 // 40 KiB).  K is split between the waves in units of P super-steps.
-template <int AK, int BKIND, int P>
+template <int AK, int BKIND, int P, bool GROUPED = false>
 __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 {
+    static_assert(!GROUPED || AK == A_F16, "group-wise scales: fp16 activations");
     constexpr int CH    = BKIND == B_I4P ? 32 : 16;
     constexpr int KS    = 4 * CH;
     constexpr int STEPS = CH / 8;
@@ -262,6 +292,14 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 #pragma unroll
     for(int i = 0; i < P; ++i)
         raw[i] = *(const u4_t*)(bptr + (size_t)i * bstep);
+    const uint16_t* sptr = (const uint16_t*)p.scale + n0 + fr; // GROUPED: scale column of this lane's weight column
+    uint16_t sraw[P];
+    if constexpr(GROUPED)
+    {
+#pragma unroll
+        for(int i = 0; i < P; ++i)
+            sraw[i] = group_scale(p, sptr, kbeg + i * KS + fq * CH);
+    }
 
     // activations: rows 0 .. M-1 of [k_begin, k_end), row pitch klen * 2 + 16 bytes
     const int pitch = klen * 2 + 16;
@@ -276,7 +314,7 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
         }
     }
     ScaleReg<AK> sc;
-    sc.set(p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>());
+    sc.set(GROUPED ? unit_scale_bits<AK>() : (p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>()));
     __syncthreads();
 
     f4_t acc            = {0.f, 0.f, 0.f, 0.f};
@@ -290,6 +328,11 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
             const u4_t w  = raw[i];
             const int nxt = min(t + i + P, nsteps - 1);
             raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * bstep);
+            if constexpr(GROUPED)
+            {
+                sc.set(sraw[i]);
+                sraw[i] = group_scale(p, sptr, kbeg + nxt * KS + fq * CH);
+            }
             u4_t af[STEPS];
 #pragma unroll
             for(int s = 0; s < STEPS; ++s)
@@ -353,9 +396,10 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 // private LDS region chunk by chunk (next chunk prefetched into registers; only the M real rows are moved, and
 // lanes of the zero rows read nothing), so there is no barrier in the loop and the footprint is 9 - 33 KiB whatever
 // K and M are.  Super-steps per wave must be a multiple of P.
-template <int AK, int BKIND, int P>
+template <int AK, int BKIND, int P, bool GROUPED = false>
 __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
 {
+    static_assert(!GROUPED || AK == A_F16, "group-wise scales: fp16 activations");
     constexpr int CH     = BKIND == B_I4P ? 32 : 16;
     constexpr int KS     = 4 * CH;
     constexpr int STEPS  = CH / 8;
@@ -388,6 +432,14 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
 #pragma unroll
     for(int i = 0; i < P; ++i)
         raw[i] = *(const u4_t*)(bptr + (size_t)i * bstep);
+    const uint16_t* sptr = (const uint16_t*)p.scale + n0 + fr; // GROUPED: scale column of this lane's weight column
+    uint16_t sraw[P];
+    if constexpr(GROUPED)
+    {
+#pragma unroll
+        for(int i = 0; i < P; ++i)
+            sraw[i] = group_scale(p, sptr, kbeg + i * KS + fq * CH);
+    }
 
     // activation chunks of this wave: piece q = lane + 64 j is 16 bytes of row q / CPR
     uint8_t* my = lds + wave * REGION;
@@ -413,7 +465,7 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
     fetch_chunk(0);
 
     ScaleReg<AK> sc;
-    sc.set(p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>());
+    sc.set(GROUPED ? unit_scale_bits<AK>() : (p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>()));
 
     f4_t acc            = {0.f, 0.f, 0.f, 0.f};
     const bool live     = fr < p.M; // this lane's activation row exists
@@ -440,6 +492,11 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
                 const u4_t w  = raw[i];
                 const int nxt = min(t + i + P, nsteps - 1);
                 raw[i]        = *(const u4_t*)(bptr + (size_t)nxt * bstep);
+                if constexpr(GROUPED)
+                {
+                    sc.set(sraw[i]);
+                    sraw[i] = group_scale(p, sptr, kbeg + nxt * KS + fq * CH);
+                }
                 u4_t af[STEPS];
 #pragma unroll
                 for(int s = 0; s < STEPS; ++s)

@@ -11,6 +11,13 @@ namespace {
 template <int AK, int BKIND, int NMB, int P>
 int launch_t(const GemmParams& gp, dim3 grid, hipStream_t s)
 {
+    // group-wise scales: fp16 activations, packed int4 or int8 weights
+    if constexpr(AK == A_F16 && BKIND != B_U8O)
+        if(gp.scale_group_k > 0)
+        {
+            hipLaunchKernelGGL((wq_gemm_skinny<AK, BKIND, NMB, P, 1, true>), grid, dim3(256), 0, s, gp);
+            return WQ_OK;
+        }
     hipLaunchKernelGGL((wq_gemm_skinny<AK, BKIND, NMB, P, 1>), grid, dim3(256), 0, s, gp);
     return WQ_OK;
 }
@@ -28,6 +35,15 @@ int launch_ab(const GemmParams& gp, dim3 grid, hipStream_t s, int nmb, int p)
 template <int AK, int BKIND, int P>
 int launch_ws_t(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
 {
+    if constexpr(AK == A_F16 && BKIND != B_U8O)
+        if(gp.scale_group_k > 0)
+        {
+            if(lds_bytes > 0)
+                hipLaunchKernelGGL((wq_gemm_skinny_ws<AK, BKIND, P, true>), grid, dim3(256), lds_bytes, s, gp);
+            else
+                hipLaunchKernelGGL((wq_gemm_skinny_wsc<AK, BKIND, P, true>), grid, dim3(256), 0, s, gp);
+            return WQ_OK;
+        }
     if(lds_bytes > 0) // whole activation image in (dynamic) LDS
         hipLaunchKernelGGL((wq_gemm_skinny_ws<AK, BKIND, P>), grid, dim3(256), lds_bytes, s, gp);
     else // chunked, per-wave regions (static LDS)

@@ -38,6 +38,7 @@ struct GemmParams
     EpilogueArgs epi;
     int scale_group_k; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
     int ld_scale;
+    int scale_group_shift; // log2(scale_group_k) when that is a power of two (small-M kernels), else -1
     int b_preshuf;     // weights in the pre-shuffled order (1 KiB blocks of 64 k x 32 columns of packed int4 or x 16
                        // columns of int8; column-block pitch = 32 * ldb_bytes or 16 * ldb_bytes): 256-tile kernels only
 };

@@ -259,7 +259,10 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     {
         const int ks        = is_i4(p->b_dtype) ? 128 : 64; // k per super-step of wq_gemm_skinny
         const int klen_all  = plan.k_end - plan.k_begin;
-        const bool eligible = is16(p->a_dtype) && !grouped && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
+        // group-wise scales: fp16 activations, groups of a power of two that cover a lane's share of a super-step
+        const bool grouped_ok = !grouped || (p->a_dtype == WQ_F16 && p->b_dtype != WQ_U8_OFFSET &&
+                                             (p->scale_group_k & (p->scale_group_k - 1)) == 0 && p->scale_group_k >= ks / 4);
+        const bool eligible = is16(p->a_dtype) && grouped_ok && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                               p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 &&
                               klen_all % ks == 0 && plan.k_begin % ks == 0 && p->lda % 8 == 0 &&
                               p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 &&
@@ -393,6 +396,15 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     return WQ_OK;
 }
 
+void set_scale_groups(wq::GemmParams& gp, const wqgemm_problem* p)
+{
+    gp.scale_group_k     = p->scale_group_k > 0 ? p->scale_group_k : 0;
+    gp.ld_scale          = p->ld_scale > 0 ? p->ld_scale : p->N;
+    gp.scale_group_shift = -1;
+    if(gp.scale_group_k > 0 && (gp.scale_group_k & (gp.scale_group_k - 1)) == 0)
+        gp.scale_group_shift = __builtin_ctz((unsigned)gp.scale_group_k);
+}
+
 wq::EpilogueArgs epilogue_of(const wqgemm_problem* p)
 {
     wq::EpilogueArgs e;
@@ -471,8 +483,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.direct_store = (p->flags & WQ_FLAG_DIRECT_STORE) ? 1 : 0;
         gp.dbg          = g_dbg;
         gp.a_scale      = p->a_dtype == WQ_F8_FNUZ ? 0x7E7E7E7E : 0x7F7F7F7F;
-        gp.scale_group_k = p->scale_group_k > 0 ? p->scale_group_k : 0;
-        gp.ld_scale      = p->ld_scale > 0 ? p->ld_scale : p->N;
+        set_scale_groups(gp, p);
         {
             // Tiles are dealt to the 8 XCDs in contiguous runs of nwg/8 (xcd_remap); inside a run the
             // walk covers group_m tile rows x (run / group_m) tile columns.  Pick the group that
@@ -544,6 +555,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.partial = plan.partial ? 1 : 0;
         gp.epi     = epilogue_of(p);
         gp.b_preshuf = is_preshuf(p->b_dtype) ? 1 : 0;
+        set_scale_groups(gp, p);
         const int nmb       = p->M <= 16 ? 1 : (p->M <= 32 ? 2 : 4);
         const int ks        = is_i4(p->b_dtype) ? 128 : 64;
         // 4 loads in flight when every slice is a whole number of 4-super-step groups
@@ -563,6 +575,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.k_begin = plan.k_begin, gp.k_end = plan.k_end;
         gp.epi     = epilogue_of(p);
         gp.b_preshuf = is_preshuf(p->b_dtype) ? 1 : 0;
+        set_scale_groups(gp, p);
         const int ks = is_i4(p->b_dtype) ? 128 : 64, klen = plan.k_end - plan.k_begin;
         // loads in flight = super-steps per unit of K dealt to a wave: as many as leave every wave at least one unit
         const int steps   = klen / ks;

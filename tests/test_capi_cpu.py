@@ -298,7 +298,12 @@ def test_group_wise_scale_validation_and_routes():
     assert "ScaleGroupK128" in capi.type_string(_problem(scale_group_k=128))
     assert capi.kernel_name(_problem(M=512, N=512, scale_group_k=64)) == "wq_gemm_mfma_128"
     assert capi.kernel_name(_problem(scale_group_k=32)) == "wq_gemm_generic"
-    assert capi.kernel_name(_problem(M=8, scale_group_k=128)) == "wq_gemm_mfma_128"     # no small-M kernel for groups yet
+    # small M: the streaming kernels take groups of a power of two that cover a lane's 32 (int4) or 16 (int8) k per super-step
+    assert capi.kernel_name(_problem(M=8, scale_group_k=128)).startswith("wq_gemm_skinny_ws")
+    assert capi.kernel_name(_problem(M=48, scale_group_k=32)) == "wq_gemm_skinny"
+    assert capi.kernel_name(_problem(M=8, scale_group_k=192)) == "wq_gemm_mfma_128"      # not a power of two
+    assert capi.kernel_name(_problem(M=8, scale_group_k=16)) == "wq_gemm_generic"        # inside a lane's 32 k
+    assert capi.kernel_name(_problem(M=8, scale_group_k=16, b_dtype=capi.I8)).startswith("wq_gemm_skinny")
     # the 256-tile kernel moves scale rows four bytes at a time: odd row strides stay on the 128-tile kernel
     assert capi.kernel_name(_problem(scale_group_k=128, ld_scale=4097)) == "wq_gemm_mfma_128"
     assert capi.kernel_name(_problem(scale_group_k=128, ld_scale=4104)) == "wq_gemm_mfma_256"

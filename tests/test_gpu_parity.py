@@ -212,6 +212,51 @@ def test_preshuffled_weights_128_tile_kernel(port, bits4):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("bits4", [True, False])
+def test_group_wise_scales_small_m_kernels(port, bits4):
+    """Group-wise weight scales in the small-M kernels (all three, with planner split-K, plain and pre-shuffled weights):
+    integer-valued inputs bit-exact against the checker (pinned by the reference's fpAintB GEMM on the expanded scale
+    tensor), decimal inputs within check_err's half tolerance, and a K slice that starts inside the matrix."""
+    rng = np.random.default_rng(47 + bits4)
+    qlo, qhi = (-8, 8) if bits4 else (-128, 128)
+    plain_dt, pre_dt = (capi.I4_PACKED, capi.I4_PRESHUFFLED) if bits4 else (capi.I8, capi.I8_PRESHUFFLED)
+
+    def layouts(q, K, N):
+        if bits4:
+            plain = pack_on_device(q, K, N)
+            return plain, preshuffle_on_device(plain, K, N)
+        plain = dev(q)
+        pre = torch.zeros(N * K, dtype=torch.int8, device="cuda")
+        capi.preshuffle_int8(plain.data_ptr(), K, K, N, pre.data_ptr(), K, torch.cuda.current_stream().cuda_stream)
+        return plain, pre
+
+    for (M, N, K, g) in ((1, 2048, 4096, 128), (8, 2048, 512, 64), (16, 4096, 8192, 128), (24, 128, 256, 32),
+                         (40, 256, 1024, 256), (64, 512, 2048, 128), (5, 4096, 16384, 128)):
+        name = capi.kernel_name(capi.fpAintB_problem(1 << 20, 1 << 20, 1 << 20, 1 << 20, M, N, K, b_dtype=plain_dt, scale_group_k=g))
+        assert name.startswith("wq_gemm_skinny"), name
+        q = rng.integers(qlo, qhi, (N, K)).astype(np.int8)
+        plain, pre = layouts(q, K, N)
+        # exact set
+        a = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+        s = f16_bits(rng.integers(1, 4, (K // g, N)).astype(np.float32))
+        exp = port.fpAintB_gemm_f16_grouped(a, q, s, M, N, K, K, K, N, g, N).reshape(M, N) if M * N * K <= 1 << 25 else None
+        got = run_fpaintb(a, plain, s, M, N, K, b_dtype=plain_dt, scale_group_k=g, expect_kernel=name)
+        got_pre = run_fpaintb(a, pre, s, M, N, K, b_dtype=pre_dt, scale_group_k=g, expect_kernel=name)
+        np.testing.assert_array_equal(got_pre, got)
+        if exp is not None:
+            np.testing.assert_array_equal(got, exp)
+        else:  # too long for the CPU checker: the 128-tile kernel (checked against it elsewhere) on the same exact inputs
+            ref = run_fpaintb(a, plain, s, M, N, K, b_dtype=plain_dt, scale_group_k=g, flags=capi.FLAG_TILE_128, expect_kernel=MFMA)
+            np.testing.assert_array_equal(got, ref)
+        # decimal set
+        if exp is not None:
+            a = f16_bits(rng.uniform(-1, 1, (M, K)))
+            s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, (K // g, N)))
+            got = run_fpaintb(a, pre, s, M, N, K, b_dtype=pre_dt, scale_group_k=g, expect_kernel=name)
+            exp = port.fpAintB_gemm_f16_grouped(a, q, s, M, N, K, K, K, N, g, N).reshape(M, N)
+            check_err(bits_to_f32(got, capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
 def test_preshuffled_weights_fp8_kernel(port):
     """The fp8 x int4 kernel on pre-shuffled weights: bit-equal to the packed run (same conversion, same MFMA order) on
     random bytes, both byte formats, a partial last row tile and split-K; exact set against the checker."""

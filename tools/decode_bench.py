@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--b", default="i4", choices=("i4", "i8"))
+    ap.add_argument("--group-k", type=int, default=0, help="group-wise weight scales: k per group (fp16 activations)")
     ap.add_argument("--pre", action="store_true", help="weights in the pre-shuffled order (random bytes either way)")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008,8192x8192,28672x8192,8192x28672")
     ap.add_argument("--ms", default="1,4,16,32,64")
@@ -64,11 +65,12 @@ def main():
         else:
             ws = [torch.randint(-128, 128, (N, K), generator=g, device=dev, dtype=torch.int8) for _ in range(copies)]
             bdt = capi.I8_PRESHUFFLED if args.pre else capi.I8
-        s = (torch.rand((N,), generator=g, device=dev) * 0.01 + 0.001).half()
+        s = (torch.rand((K // args.group_k, N) if args.group_k else (N,), generator=g, device=dev) * 0.01 + 0.001).half()
         for M in (int(v) for v in args.ms.split(",")):
             a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).half()
             c = torch.empty((M, N), dtype=torch.float16, device=dev)
-            probs = [capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K, b_dtype=bdt)
+            probs = [capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K, b_dtype=bdt,
+                                          scale_group_k=args.group_k)
                      for w in ws]
             nb = max(capi.workspace_bytes(p) for p in probs)
             wsp = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
@@ -102,7 +104,7 @@ def main():
             line = {"N": N, "K": K, "M": M, "b": args.b + ("_preshuffled" if args.pre else ""), "kernel": capi.kernel_name(probs[0]), "us": ms * 1e3,
                     "algorithmic_bytes": nbytes, "hbm_gbps": nbytes / (ms * 1e-3) / 1e9,
                     "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM, "weight_copies_rotated": copies,
-                    "hip_graph": bool(args.graph)}
+                    "hip_graph": bool(args.graph), "scale_group_k": args.group_k}
             print(json.dumps(line), flush=True)
             lines.append(line)
         del ws
