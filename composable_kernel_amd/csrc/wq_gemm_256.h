@@ -124,7 +124,7 @@ __device__ __forceinline__ void dequant8_i4_f16_stage(u4_t& v, const ScaleReg<A_
 // cycles spent working and the cycles spent waiting at the section's barrier, and writes the sums to
 // p.dbg (no output value depends on them; the product never launches this instantiation).
 //
-// GROUPED (SCHED 5, fp16 activations): group-wise weight scales, groups of a multiple of 64 consecutive k, so a K
+// GROUPED (SCHED 5): group-wise weight scales, groups of a multiple of 64 consecutive k, so a K
 // tile lies inside one group.  The scales of a wave's own columns travel with the tile: one more LDS-DMA piece
 // (4 bytes per lane) behind the first part of tile t+2's pieces in L0(t), into a private 256-byte LDS area per wave and
 // tile parity behind the ring; the counted vmcnt waits allow one more operation in flight.  The scale registers are
@@ -134,7 +134,7 @@ constexpr int kGroupScaleLds = 8 * 2 * 256; // bytes of dynamic LDS behind Mfma2
 template <int AK, int BKIND, int WM, int SCHED, bool STAMP = false, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void wq_gemm_mfma_256(const GemmParams p)
 {
-    static_assert(!GROUPED || (SCHED == 5 && AK == A_F16), "group-wise scales: default schedule, fp16 activations");
+    static_assert(!GROUPED || SCHED == 5, "group-wise scales: default schedule");
     using T = Mfma256<BKIND>;
     constexpr int WN = 8 / WM;        // waves along N
     constexpr int MT = 256 / WM / 16; // accumulator tiles along M per wave: 8 or 16

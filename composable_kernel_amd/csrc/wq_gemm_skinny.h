@@ -51,7 +51,7 @@ __device__ __forceinline__ const uint8_t* weight_stream(const GemmParams& p, int
     return (const uint8_t*)p.b + (size_t)col * p.ldb_bytes + (size_t)kbeg / 8 * BInfo<BKIND>::kBytesPer8K + fq * 16;
 }
 
-// Group-wise scales in the small-M kernels (GROUPED instances; fp16 activations, groups of a power of two of at least the
+// Group-wise scales in the small-M kernels (GROUPED instances; groups of a power of two of at least the
 // 32 (packed int4) or 16 (int8) k a lane takes from one super-step, so that a lane's weights of a super-step share one
 // scale): the scale of (column, super-step) travels with that super-step's weights -- fetched P super-steps ahead from
 // the (L2-resident) scale rows and installed right before the dequantisation.
@@ -68,7 +68,6 @@ __device__ __forceinline__ uint16_t group_scale(const GemmParams& p, const uint1
 template <int AK, int BKIND, int NMB, int P, int NB, bool GROUPED = false>
 __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 {
-    static_assert(!GROUPED || AK == A_F16, "group-wise scales: fp16 activations");
     constexpr int CH     = BKIND == B_I4P ? 32 : 16; // k per lane per super-step (16 bytes of weights)
     constexpr int KS     = 4 * CH;                   // k per super-step
     constexpr int STEPS  = CH / 8;                   // MFMA k-steps per super-step
@@ -265,7 +264,6 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny(const GemmParams p)
 template <int AK, int BKIND, int P, bool GROUPED = false>
 __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 {
-    static_assert(!GROUPED || AK == A_F16, "group-wise scales: fp16 activations");
     constexpr int CH    = BKIND == B_I4P ? 32 : 16;
     constexpr int KS    = 4 * CH;
     constexpr int STEPS = CH / 8;
@@ -399,7 +397,6 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
 template <int AK, int BKIND, int P, bool GROUPED = false>
 __global__ __launch_bounds__(256) void wq_gemm_skinny_wsc(const GemmParams p)
 {
-    static_assert(!GROUPED || AK == A_F16, "group-wise scales: fp16 activations");
     constexpr int CH     = BKIND == B_I4P ? 32 : 16;
     constexpr int KS     = 4 * CH;
     constexpr int STEPS  = CH / 8;

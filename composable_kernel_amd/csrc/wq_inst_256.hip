@@ -48,7 +48,7 @@ int WQ_CAT(WQ_INST_AK, WQ_INST_BK)(const GemmParams& gp, dim3 grid, hipStream_t 
                                                  : launch_v<AK, BK, 1, 5, true>(gp, grid, s);
 #endif
 #endif
-#if WQ_INST_AK == 0 && !defined(WQ_INST_MINIMAL)
+#if !defined(WQ_INST_MINIMAL)
     if(gp.scale_group_k > 0) // group-wise scales: the default schedule and wave grid only
         return launch_v<AK, BK, 1, 5, false, true>(gp, grid, s);
 #endif

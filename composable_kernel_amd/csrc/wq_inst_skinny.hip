@@ -11,8 +11,8 @@ namespace {
 template <int AK, int BKIND, int NMB, int P>
 int launch_t(const GemmParams& gp, dim3 grid, hipStream_t s)
 {
-    // group-wise scales: fp16 activations, packed int4 or int8 weights
-    if constexpr(AK == A_F16 && BKIND != B_U8O)
+    // group-wise scales: packed int4 or int8 weights
+    if constexpr(BKIND != B_U8O)
         if(gp.scale_group_k > 0)
         {
             hipLaunchKernelGGL((wq_gemm_skinny<AK, BKIND, NMB, P, 1, true>), grid, dim3(256), 0, s, gp);
@@ -35,7 +35,7 @@ int launch_ab(const GemmParams& gp, dim3 grid, hipStream_t s, int nmb, int p)
 template <int AK, int BKIND, int P>
 int launch_ws_t(const GemmParams& gp, dim3 grid, int lds_bytes, hipStream_t s)
 {
-    if constexpr(AK == A_F16 && BKIND != B_U8O)
+    if constexpr(BKIND != B_U8O)
         if(gp.scale_group_k > 0)
         {
             if(lds_bytes > 0)

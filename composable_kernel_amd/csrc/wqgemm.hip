@@ -225,8 +225,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     {
         if(!p->scale)
             return fail(WQ_ERR_INVALID, "group-wise scales need the scale tensor");
-        if(p->a_dtype != WQ_F16)
-            return fail(WQ_ERR_UNSUPPORTED, "group-wise scales are implemented for fp16 activations");
+        if(!is16(p->a_dtype))
+            return fail(WQ_ERR_UNSUPPORTED, "group-wise scales go with fp16 or bf16 activations");
         if(p->ld_scale != 0 && p->ld_scale < p->N)
             return fail(WQ_ERR_INVALID, "ld_scale too small");
     }
@@ -260,7 +260,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         const int ks        = is_i4(p->b_dtype) ? 128 : 64; // k per super-step of wq_gemm_skinny
         const int klen_all  = plan.k_end - plan.k_begin;
         // group-wise scales: fp16 activations, groups of a power of two that cover a lane's share of a super-step
-        const bool grouped_ok = !grouped || (p->a_dtype == WQ_F16 && p->b_dtype != WQ_U8_OFFSET &&
+        const bool grouped_ok = !grouped || (p->b_dtype != WQ_U8_OFFSET &&
                                              (p->scale_group_k & (p->scale_group_k - 1)) == 0 && p->scale_group_k >= ks / 4);
         const bool eligible = is16(p->a_dtype) && grouped_ok && p->M <= 64 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                               p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 &&
@@ -421,12 +421,11 @@ wq::EpilogueArgs epilogue_of(const wqgemm_problem* p)
 template <int AK, int BKIND>
 void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
 {
-    if constexpr(AK == wq::A_F16)
-        if(gp.scale_group_k > 0)
-        {
-            hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND, true>), grid, dim3(256), 0, s, gp);
-            return;
-        }
+    if(gp.scale_group_k > 0)
+    {
+        hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND, true>), grid, dim3(256), 0, s, gp);
+        return;
+    }
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
 }
 

@@ -26,7 +26,7 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
 
     x (M, K) fp16 / bf16, row-major; weight uint8 (N, K/2) packed int4 (bits = 4) or int8 (N, K) (bits = 8);
     scale and bias (N,) of x's dtype; epilogue in {"none", "fastgelu", "add", "add_fastgelu"}.
-    Group-wise scales (fp16 only): scale of shape (G, N), one row per group of K / G consecutive k."""
+    Group-wise scales: scale of shape (G, N), one row per group of K / G consecutive k."""
     if not x.is_cuda:
         raise RuntimeError("wqgemm::fpaintb_linear runs on the GPU only")
     if x.dtype not in _DT or scale.dtype != x.dtype:
@@ -47,8 +47,6 @@ def fpaintb_linear(x: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor, b
     if scale.dim() == 2:
         if scale.shape[0] == 0 or K % scale.shape[0] != 0:
             raise ValueError(f"K = {K} is not a whole number of the {scale.shape[0]} scale groups")
-        if x.dtype != torch.float16:
-            raise TypeError("group-wise scales need float16 activations")
         group_k = K // scale.shape[0]
     # the kernels read weight / scale / bias through raw pointers: shapes, dtypes, devices and contiguity are checked here
     want = (N, K // 2) if bits == 4 else (N, K)

@@ -137,9 +137,11 @@ typedef struct wqgemm_problem
      * ReferencefpAintBGemm (library/include/ck/library/reference_tensor_operation/cpu/reference_fpAintB_gemm.hpp:62-127)
      * with rows repeating g times, per-channel scales being its strides-(0,1) case; the (K / block, N) shape follows
      * the B1 scale tensor of example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:126-152.
-     * fp16 activations only.  Any g >= 1 runs on the general kernel; g a multiple of 64 (64, 128, ...) on the
-     * 128- and 256-tile matrix-core kernels.  k (and so the group index) counts from the start of the K range also
-     * for K slices and split-K. */
+     * With bf16 activations it is the B1 operand of the Multiply-on-B form
+     * (example/60_gemm_multi_ABD/gemm_multi_ABD_xdl_fastgelu_bf16_i8.cpp:137-139) with rows that repeat per group instead
+     * of a zero stride.  fp16 and bf16 activations.  Any g >= 1 runs on the general kernel; g a multiple of 64 (64, 128,
+     * ...) on the 128- and 256-tile matrix-core kernels; g a power of two >= 32 (packed int4) or >= 16 (int8) on the
+     * small-M kernels.  k (and so the group index) counts from the start of the K range also for K slices and split-K. */
     int32_t scale_group_k, ld_scale;
 } wqgemm_problem;
 

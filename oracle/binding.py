@@ -90,6 +90,8 @@ class Checker:
                         [_i8p, _i8p, C.c_void_p, _i8p] + [C.c_int] * 6 + [C.c_float, C.c_int] + tail)
         self._bf16 = sig("gemm_bf16_i8", None,
                          [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p] + tail)
+        self._bf16_g = sig("gemm_bf16_i8_grouped", None,
+                           [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + tail)
         self._f8 = sig("gemm_f8_i8_mm", None, [_u8p, _i8p, _f32p, _f32p, _u16p] + [C.c_int] * 7 + tail)
         self._bf16_dmat = sig("gemm_bf16_i8_dmat", None,
                               [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 +
@@ -162,6 +164,18 @@ class Checker:
         pb1 = np.ascontiguousarray(b1, np.uint16).ctypes.data if b1 is not None else None  # None: B = PassThrough(b0)
         self._bf16(a.ravel(), b0.ravel(), pb1, e, M, N, K, lda, b_sk, b_sn, lde, epilogue, p0, p1,
                    *self._t(nthreads))
+        return e
+
+    def gemm_bf16_i8_grouped(self, a, b0, b1, M, N, K, lda, b_sk, b_sn, lde, epilogue, group_k, ld_b1=None, d0=None,
+                             d1=None, nthreads=None) -> np.ndarray:
+        """gemm_bf16_i8 with group-wise scales: b1 uint16 (ceil(K / group_k), ld_b1), one row of N scales per group."""
+        ld_b1 = ld_b1 or N
+        e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.uint16)
+        p0 = d0.ctypes.data if d0 is not None else None
+        p1 = d1.ctypes.data if d1 is not None else None
+        b1 = np.ascontiguousarray(b1, np.uint16)
+        self._bf16_g(a.ravel(), b0.ravel(), b1.ctypes.data, e, M, N, K, lda, b_sk, b_sn, lde, epilogue, p0, p1, group_k, ld_b1,
+                     *self._t(nthreads))
         return e
 
     def gemm_bf16_i8_dmat(self, a, b0, b1, M, N, K, lda, b_sk, b_sn, lde, epilogue, d0, ldd0, d1=None, ldd1=0,

@@ -316,6 +316,46 @@ void ckref_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1,
         }
 }
 
+// The same path with a B1 tensor of lengths (K, N) and strides (N, 1) whose row k holds the scales of group k / group_k
+// (rows of the caller's (K / group_k, ld_b1) array repeated): Multiply on B element by element, then ReferenceGemm.
+void ckref_gemm_bf16_i8_grouped(const uint16_t* a, const int8_t* b0, const uint16_t* b1, uint16_t* e, int M, int N, int K,
+                                int lda, int b_sk, int b_sn, int lde, int epilogue, const uint16_t* d0, const uint16_t* d1,
+                                int group_k, int ld_b1)
+{
+    auto ta  = load2<bhalf_t>(a, M, K, lda, 1);
+    auto tb0 = load2<int8_t>(b0, K, N, b_sk, b_sn);
+    Tensor<bhalf_t> tb1(desc2(K, N, N, 1));
+    for(int k = 0; k < K; ++k)
+        for(int n = 0; n < N; ++n)
+            tb1(k, n) = bhalf_t(b1[(size_t)(k / group_k) * ld_b1 + n]);
+    Tensor<bhalf_t> tb(desc2(K, N, b_sk, b_sn));
+    for(int n = 0; n < N; ++n)
+        for(int k = 0; k < K; ++k)
+            ew::Multiply{}(tb(k, n), tb0(k, n), tb1(k, n));
+    Tensor<float> tc(desc2(M, N, N, 1));
+    using Ref = ck::tensor_operation::host::ReferenceGemm<bhalf_t, bhalf_t, float, float, PT, PT, PT>;
+    auto ref = Ref{};
+    auto inv = ref.MakeInvoker();
+    inv.Run(ref.MakeArgument(ta, tb, tc, PT{}, PT{}, PT{}));
+    for(int m = 0; m < M; ++m)
+        for(int n = 0; n < N; ++n)
+        {
+            bhalf_t y;
+            if(epilogue == 0)
+                PT{}(y, tc(m, n));
+            else if(epilogue == 1)
+                ew::FastGelu{}(y, tc(m, n));
+            else if(epilogue == 3)
+                ew::Add{}(y, tc(m, n), bhalf_t(d0[n]));
+            else if(epilogue == 4)
+                ew::AddFastGelu{}(y, tc(m, n), bhalf_t(d0[n]));
+            else
+                ew::ConvertBF16RTN{}(y, tc(m, n));
+            (void)d1;
+            e[static_cast<size_t>(m) * lde + n] = y;
+        }
+}
+
 // Same path with the D tensors addressed as the examples' d_m_n(m, n) over a row-major (M, N) descriptor of row
 // stride ldd (example/60_gemm_multi_ABD/gemm_multi_ABD_xdl_bias_fastgelu_bf16_i8.cpp:86,140,263); 0 = per column.
 void ckref_gemm_bf16_i8_dmat(const uint16_t* a, const int8_t* b0, const uint16_t* b1, uint16_t* e,

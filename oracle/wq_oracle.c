@@ -540,6 +540,7 @@ typedef struct
     const uint16_t *d0, *d1;
     int K, lda, b_sk, b_sn, lde, epilogue;
     int ldd0, ldd1;
+    int group_k, ld_b1; /* group_k > 0: b1 holds one row of scales per group_k consecutive k, rows ld_b1 apart */
 } bf16_ctx;
 
 static void bf16_i8_mn(void* p, int m, int n)
@@ -550,7 +551,8 @@ static void bf16_i8_mn(void* p, int m, int n)
     {
         const float va = wqo_bf16_to_f32(x->a[(size_t)m * x->lda + k]);
         const int8_t q = x->b0[(size_t)k * x->b_sk + (size_t)n * x->b_sn];
-        const float vb = x->b1 ? wqo_bf16_to_f32(wqo_multiply_bf16(q, x->b1[n])) : (float)q;
+        const uint16_t* b1 = x->b1 && x->group_k > 0 ? x->b1 + (size_t)(k / x->group_k) * x->ld_b1 : x->b1;
+        const float vb     = b1 ? wqo_bf16_to_f32(wqo_multiply_bf16(q, b1[n])) : (float)q;
         acc += va * vb;
     }
     const uint16_t* d0 = x->d0 ? x->d0 + (size_t)m * x->ldd0 : 0;
@@ -581,7 +583,18 @@ void wqo_gemm_bf16_i8(const uint16_t* a, const int8_t* b0, const uint16_t* b1, u
                       int N, int K, int lda, int b_sk, int b_sn, int lde, int epilogue,
                       const uint16_t* d0, const uint16_t* d1, int nthreads)
 {
-    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue, 0, 0};
+    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue, 0, 0, 0, 0};
+    parallel_mn(bf16_i8_mn, &x, M, N, nthreads);
+}
+
+/* The same verify path with a B1 that varies along k: the Multiply functor (binary_element_wise_operation.hpp:182-190) sees
+ * b1(k, n) = scale row k / group_k (one row of N bhalf scales per group_k consecutive k, rows ld_b1 apart) -- the (K, N)
+ * B1 tensor of gemm_multi_ABD_xdl_fastgelu_bf16_i8.cpp:137-139 with rows that repeat per group instead of a stride of 0. */
+void wqo_gemm_bf16_i8_grouped(const uint16_t* a, const int8_t* b0, const uint16_t* b1, uint16_t* e, int M, int N, int K,
+                              int lda, int b_sk, int b_sn, int lde, int epilogue, const uint16_t* d0, const uint16_t* d1,
+                              int group_k, int ld_b1, int nthreads)
+{
+    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue, 0, 0, group_k, ld_b1};
     parallel_mn(bf16_i8_mn, &x, M, N, nthreads);
 }
 
@@ -590,7 +603,7 @@ void wqo_gemm_bf16_i8_dmat(const uint16_t* a, const int8_t* b0, const uint16_t* 
                            int N, int K, int lda, int b_sk, int b_sn, int lde, int epilogue,
                            const uint16_t* d0, int ldd0, const uint16_t* d1, int ldd1, int nthreads)
 {
-    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue, ldd0, ldd1};
+    bf16_ctx x = {a, b0, b1, e, d0, d1, K, lda, b_sk, b_sn, lde, epilogue, ldd0, ldd1, 0, 0};
     parallel_mn(bf16_i8_mn, &x, M, N, nthreads);
 }
 

@@ -268,6 +268,29 @@ def gemm_cases(ref) -> dict:
     a_tie = bf16_bits_trunc(rng.integers(-3, 4, (M, K)).astype(np.float32) * 0.5)
     out["rtn_a_tie"] = a_tie
     out["bf16_tie_e_row_ep8"] = ref.gemm_bf16_i8(a_tie, brow, None, M, N, K, K, N, 1, N, 8, None, None)
+
+    # ---- group-wise weight scales with bf16 activations: Multiply on B with a B1 tensor whose row k holds the scales of
+    # group k / group_k (example/60's (K, N) B1 with repeating rows instead of a zero stride), ReferenceGemm, epilogue.
+    # int8 and int4-range weights, groups of 64 / 128 / 32, a padded scale row, PassThrough / FastGelu / Add / RTN.
+    def grouped_bf16(tag, M, N, K, group_k, ld_b1, qlo, qhi, ep, integer=False):
+        groups = (K + group_k - 1) // group_k
+        if integer:
+            a = bf16_bits_trunc(np.round(rng.uniform(-2, 2, (M, K))))
+            s = bf16_bits_trunc(rng.integers(1, 4, (groups, ld_b1)).astype(np.float32))
+        else:
+            a = bf16_bits_trunc(rng.uniform(-1, 1, (M, K)))
+            s = bf16_bits_trunc(rng.uniform(2.0 ** -8, 2.0 ** -4, (groups, ld_b1)))
+        b = rng.integers(qlo, qhi + 1, (N, K)).astype(np.int8)
+        d0 = bf16_bits_trunc(rng.uniform(-0.5, 0.5, N))
+        out[f"{tag}_shape"] = np.array([M, N, K, group_k, ld_b1, ep], np.int32)
+        out[f"{tag}_a"], out[f"{tag}_b"], out[f"{tag}_s"], out[f"{tag}_d0"] = a, b, s, d0
+        out[f"{tag}_e"] = ref.gemm_bf16_i8_grouped(a, b, s, M, N, K, K, 1, K, N, ep, group_k, ld_b1, d0, None)
+
+    grouped_bf16("bgrp64_i8", 48, 64, 256, 64, 64, -128, 127, 0)
+    grouped_bf16("bgrp128_i4", 48, 64, 256, 128, 72, -8, 7, 1)
+    grouped_bf16("bgrp32_i8_add", 33, 24, 96, 32, 24, -128, 127, 3)
+    grouped_bf16("bgrp64_i4_rtn", 32, 48, 128, 64, 48, -8, 7, 8)
+    grouped_bf16("bgrp128_int_i4", 128, 128, 512, 128, 128, -8, 7, 0, integer=True)
     return out
 
 

@@ -310,8 +310,10 @@ def test_group_wise_scale_validation_and_routes():
     assert not capi.is_supported(_problem(scale_group_k=128, ld_scale=4000))            # shorter than a row of N scales
     assert not capi.is_supported(_problem(scale_group_k=-1))
     assert not capi.is_supported(_problem(scale_group_k=128, scale=None))
-    assert not capi.is_supported(_problem(scale_group_k=128, a_dtype=capi.BF16))        # fp16 activations only
-    assert b"fp16" in capi.lib.wqgemm_last_error()
+    assert capi.kernel_name(_problem(scale_group_k=128, a_dtype=capi.BF16)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(M=8, scale_group_k=128, a_dtype=capi.BF16, b_dtype=capi.I8)).startswith("wq_gemm_skinny")
+    f8 = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=0x10000, d1=0x10000)
+    assert not capi.is_supported(_problem(scale_group_k=128, **f8))                     # fp8: scales live in the epilogue
 
 
 def test_problem_struct_size_handshake():

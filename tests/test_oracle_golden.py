@@ -305,3 +305,22 @@ def test_convert_bf16_rtn(port, golden_scalars, golden_gemm):
     np.testing.assert_array_equal(e, g["bf16_mul_e_row_ep8"])
     e = port.gemm_bf16_i8(g["rtn_a_tie"], brow, None, M, N, K, K, N, 1, N, 8)
     np.testing.assert_array_equal(e, g["bf16_tie_e_row_ep8"])
+
+
+BF16_GROUPED_CASES = ("bgrp64_i8", "bgrp128_i4", "bgrp32_i8_add", "bgrp64_i4_rtn", "bgrp128_int_i4")
+
+
+def test_grouped_scale_cases_bf16(port, golden_gemm):
+    """Group-wise weight scales with bf16 activations: the checker against the reference's Multiply-on-B functor applied
+    with a B1 tensor whose rows repeat per group, ReferenceGemm and the epilogue functors (PassThrough, FastGelu, Add,
+    ConvertBF16RTN)."""
+    g = golden_gemm
+    for tag in BF16_GROUPED_CASES:
+        M, N, K, group_k, ld_b1, ep = (int(v) for v in g[f"{tag}_shape"])
+        e = port.gemm_bf16_i8_grouped(g[f"{tag}_a"], g[f"{tag}_b"], g[f"{tag}_s"], M, N, K, K, 1, K, N, ep, group_k, ld_b1,
+                                      g[f"{tag}_d0"])
+        np.testing.assert_array_equal(e, g[f"{tag}_e"])
+    # one group spanning all of K is the per-channel GEMM
+    M, N, K = 48, 64, 128
+    e = port.gemm_bf16_i8_grouped(g["bf16_a"], g["bf16_bcol"], g["bf16_s"][None, :], M, N, K, K, 1, K, N, 0, K, N)
+    np.testing.assert_array_equal(e, g["bf16_e_col_ep0"])

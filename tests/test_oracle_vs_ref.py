@@ -88,3 +88,14 @@ def test_grouped_scales_random(port, ref):
         s = rng.uniform(2.0 ** -8, 2.0 ** -4, (groups, N + 4)).astype(np.float16).view(np.uint16)
         np.testing.assert_array_equal(port.fpAintB_gemm_f16_grouped(a, b, s, M, N, K, K, K, N, g, N + 4),
                                       ref.fpAintB_gemm_f16_grouped(a, b, s, M, N, K, K, K, N, g, N + 4))
+
+
+def test_grouped_scales_bf16_random(port, ref):
+    rng = np.random.default_rng(13)
+    for M, N, K, gk, ep in ((9, 24, 160, 32, 0), (20, 40, 256, 128, 1), (5, 16, 96, 64, 3), (12, 32, 128, 64, 8)):
+        a = (rng.uniform(-1, 1, (M, K)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        s = (rng.uniform(0.004, 0.06, ((K + gk - 1) // gk, N)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        d0 = (rng.uniform(-0.5, 0.5, N).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        np.testing.assert_array_equal(port.gemm_bf16_i8_grouped(a, b, s, M, N, K, K, 1, K, N, ep, gk, N, d0),
+                                      ref.gemm_bf16_i8_grouped(a, b, s, M, N, K, K, 1, K, N, ep, gk, N, d0))
