@@ -18,10 +18,15 @@ q = torch.randint(-8, 8, (N, K), generator=g, device=dev, dtype=torch.int8)
 b = torch.empty((N, K // 2), dtype=torch.uint8, device=dev)
 sp = torch.cuda.current_stream().cuda_stream
 capi.pack_int4(q.data_ptr(), K, K, N, b.data_ptr(), K // 2, sp)
+bdt = capi.I4_PACKED
+if os.environ.get("WQ_PRESHUFFLE", "1") != "0":  # the weights in the pre-shuffled order (the deployed form)
+    b2 = torch.empty_like(b)
+    capi.preshuffle_int4(b.data_ptr(), K // 2, K, N, b2.data_ptr(), K, sp)
+    b, bdt = b2, capi.I4_PRESHUFFLED
 d0 = torch.rand((N,), generator=g, device=dev)
 d1 = torch.rand((M,), generator=g, device=dev)
 c = torch.empty((M, N), dtype=torch.float16, device=dev)
-p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16,
+p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_E4M3FN, b_dtype=bdt, c_dtype=capi.F16,
                          epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU, d0=d0.data_ptr(), d1=d1.data_ptr())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for _ in range(n):
