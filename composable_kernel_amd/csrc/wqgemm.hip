@@ -327,7 +327,17 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     // fp8 activations x packed int4 weights on the fp8 matrix core (scales arrive through the epilogue).
     // FNUZ bytes qualify only when the caller excludes the three encodings E4M3FN cannot express.
     const bool is_f8 = p->a_dtype == WQ_F8_FNUZ || p->a_dtype == WQ_F8_E4M3FN;
-    if(is_f8 && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
+    // The fp8 kernel and the 32x32-MFMA kernel address A and B through buffer resources with 32-bit byte offsets: at most
+    // 2 GiB per operand there (the bound the reference puts on every operand,
+    // include/ck/tensor_operation/gpu/grid/gridwise_fpAintB_gemm_wmma.hpp:501-507); the other kernels index with 64 bits.
+    const uint64_t a_span = ((uint64_t)(p->a_layout == WQ_ROW_MAJOR ? p->M : p->K) - 1) * (uint64_t)p->lda +
+                            (uint64_t)(p->a_layout == WQ_ROW_MAJOR ? p->K : p->M);
+    const uint64_t b_div  = is_i4(p->b_dtype) ? 2 : 1; // elements per byte
+    const uint64_t b_span = preshuf                         ? (uint64_t)p->N * (uint64_t)p->ldb / b_div
+                            : p->b_layout == WQ_COL_MAJOR ? (((uint64_t)p->N - 1) * (uint64_t)p->ldb + (uint64_t)p->K) / b_div
+                                                          : (((uint64_t)p->K - 1) * (uint64_t)p->ldb + (uint64_t)p->N) / b_div;
+    const bool fits_32bit = a_span * (is_f8 || p->a_dtype == WQ_I8 ? 1 : 2) <= 0x7FFFFFFFull && b_span <= 0x7FFFFFFFull;
+    if(is_f8 && fits_32bit && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
        is_i4(p->b_dtype) && !(preshuf && (p->flags & WQ_FLAG_PINGPONG)) && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->M > 64 && p->N % 256 == 0 &&
        plan.k_begin % 128 == 0 && plan.k_per_z % 128 == 0 && (plan.k_end - plan.k_begin) % 128 == 0 &&
        p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
@@ -387,6 +397,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_UNSUPPORTED,
                     "pre-shuffled B runs on the matrix-core kernels only: K-contiguous 16-byte aligned operands, K in whole "
                     "64-k tiles (128 for fp8 activations, which also need N %% 256 == 0), scale groups of a multiple of 64 k");
+    if((p->flags & WQ_FLAG_MFMA_32X32) && plan.route == ROUTE_MFMA256 && !fits_32bit)
+        return fail(WQ_ERR_UNSUPPORTED, "the 32x32-MFMA kernel addresses at most 2 GiB of A and of B");
     if(preshuf && (p->flags & WQ_FLAG_MFMA_32X32))
         return fail(WQ_ERR_UNSUPPORTED, "pre-shuffled B: the 32x32-MFMA kernel does not read this layout");
     if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_MFMA256)

@@ -319,3 +319,18 @@ def test_group_wise_scale_validation_and_routes():
 def test_problem_struct_size_handshake():
     # the binding refuses a library built with another wqgemm_problem (it checks at load time); here: they agree
     assert capi.lib.wqgemm_problem_size() == C.sizeof(capi.Problem)
+
+
+def test_operands_beyond_2_gib_stay_off_the_32_bit_kernels():
+    """The fp8 kernel and the 32x32-MFMA kernel address A and B with 32-bit byte offsets, so an operand above 2 GiB
+    (the bound of include/ck/tensor_operation/gpu/grid/gridwise_fpAintB_gemm_wmma.hpp:501-507) is kept away from
+    them; the kernels with 64-bit addressing take such operands."""
+    f8 = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, scale=None, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=0x10000, d1=0x10000)
+    assert capi.kernel_name(_problem(M=(1 << 19) - 256, **f8)) == "wq_gemm_f8_mfma_256"  # A just below 2 GiB
+    assert capi.kernel_name(_problem(M=1 << 19, **f8)) == "wq_gemm_generic"              # A of exactly 2 GiB
+    assert capi.kernel_name(_problem(N=1 << 20, K=8192, lda=8192, ldb=8192, **f8)) == "wq_gemm_generic"   # B = 4 GiB
+    assert capi.kernel_name(_problem(N=1 << 20, K=8192, lda=8192, ldb=8192, b_dtype=capi.I4_PRESHUFFLED)) == "wq_gemm_mfma_256"
+    assert capi.kernel_name(_problem(M=1 << 20)) == "wq_gemm_mfma_256"                   # fp16 A of 8 GiB: 64-bit addressing
+    assert capi.is_supported(_problem(M=(1 << 18) - 256, flags=capi.FLAG_MFMA_32X32))
+    assert not capi.is_supported(_problem(M=1 << 20, flags=capi.FLAG_MFMA_32X32))
+    assert b"2 GiB" in capi.lib.wqgemm_last_error()
