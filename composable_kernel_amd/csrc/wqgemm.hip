@@ -397,6 +397,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         return fail(WQ_ERR_UNSUPPORTED,
                     "pre-shuffled B runs on the matrix-core kernels only: K-contiguous 16-byte aligned operands, K in whole "
                     "64-k tiles (128 for fp8 activations, which also need N %% 256 == 0), scale groups of a multiple of 64 k");
+    if(plan.route == ROUTE_GENERIC && (p->M + 15) / 16 > 65535)
+        return fail(WQ_ERR_UNSUPPORTED, "the general kernel takes at most 1048560 rows (M = %d)", p->M);
     if((p->flags & WQ_FLAG_MFMA_32X32) && plan.route == ROUTE_MFMA256 && !fits_32bit)
         return fail(WQ_ERR_UNSUPPORTED, "the 32x32-MFMA kernel addresses at most 2 GiB of A and of B");
     if(preshuf && (p->flags & WQ_FLAG_MFMA_32X32))

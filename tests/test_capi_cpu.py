@@ -334,3 +334,11 @@ def test_operands_beyond_2_gib_stay_off_the_32_bit_kernels():
     assert capi.is_supported(_problem(M=(1 << 18) - 256, flags=capi.FLAG_MFMA_32X32))
     assert not capi.is_supported(_problem(M=1 << 20, flags=capi.FLAG_MFMA_32X32))
     assert b"2 GiB" in capi.lib.wqgemm_last_error()
+
+
+def test_general_kernel_row_limit():
+    # its grid holds M / 16 in a 16-bit dimension: refused by validation, not by a failed launch
+    assert capi.is_supported(_problem(M=1048560, flags=capi.FLAG_GENERIC))
+    assert not capi.is_supported(_problem(M=1048561, flags=capi.FLAG_GENERIC))
+    assert b"1048560 rows" in capi.lib.wqgemm_last_error()
+    assert capi.is_supported(_problem(M=1 << 21))       # the tile kernels index tiles in one 32-bit grid dimension
