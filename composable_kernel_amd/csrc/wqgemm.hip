@@ -165,7 +165,9 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
     plan.partial = slice || kb > 1;
     plan.to_c    = slice;
     const int klen = plan.k_end - plan.k_begin;
-    plan.k_per_z   = kb > 1 ? wqgemm_splitk_kread(klen, kb, 64) : klen;
+    // (slices in whole K tiles of the kernel that will run them: 128 k on the fp8 matrix core, 64 k elsewhere)
+    const int k_tile = p->a_dtype == WQ_F8_FNUZ || p->a_dtype == WQ_F8_E4M3FN ? 128 : 64;
+    plan.k_per_z     = kb > 1 ? wqgemm_splitk_kread(klen, kb, k_tile) : klen;
     // (trailing slices may be empty when K is small: they store zero partials)
     if(plan.partial && (p->N % 4 != 0 || p->ldc % 4 != 0))
         return fail(WQ_ERR_UNSUPPORTED, "split-K needs N and ldc to be multiples of 4");

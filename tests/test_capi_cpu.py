@@ -342,3 +342,13 @@ def test_general_kernel_row_limit():
     assert not capi.is_supported(_problem(M=1048561, flags=capi.FLAG_GENERIC))
     assert b"1048560 rows" in capi.lib.wqgemm_last_error()
     assert capi.is_supported(_problem(M=1 << 21))       # the tile kernels index tiles in one 32-bit grid dimension
+
+
+def test_caller_split_k_of_fp8_activations_stays_on_the_fp8_kernel():
+    # slices are cut in the fp8 kernel's 128-deep K tiles, whatever k_batch is (2048 / 3 in 64-deep tiles would not be)
+    f8 = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, scale=None, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=0x10000, d1=0x10000)
+    for K in (1024, 2048, 4096):
+        for kb in (2, 3, 5, 7):
+            for b_dtype in (capi.I4_PACKED, capi.I4_PRESHUFFLED):
+                p = _problem(K=K, lda=K, ldb=K, k_batch=kb, b_dtype=b_dtype, **f8)
+                assert capi.kernel_name(p) == "wq_gemm_f8_mfma_256", (K, kb)

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Time-bounded random sweep over the fp16 / bf16 x int4 / int8 problem space of the C ABI.
+
+Every case runs whatever kernel the dispatcher picks (tile kernels, small-M kernels, split-K with or without a
+workspace, plain or pre-shuffled weights, per-channel or group-wise scales, every 16-bit epilogue, padded leading
+dimensions) and the general kernel on the plain weight layout; on integer-valued inputs, whose fp32 sums are exact in
+any order, the two outputs must be the same bits, and bytes of C outside the M x N block must stay untouched.
+
+    python tools/fuzz_routes.py --seconds 300 --seed 1 --out gpurun_out/fuzz.json
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from composable_kernel_amd import capi  # noqa: E402
+from gpu_util import bf16_bits, dev, f16_bits, pack_on_device, run_fpaintb  # noqa: E402
+
+EPILOGUES = [("passthrough", capi.EPI_PASSTHROUGH, 0), ("fastgelu", capi.EPI_FASTGELU, 0), ("add", capi.EPI_ADD, 1),
+             ("add_fastgelu", capi.EPI_ADD_FASTGELU, 1), ("multiply", capi.EPI_MULTIPLY, 1),
+             ("multiply_fastgelu", capi.EPI_MULTIPLY_FASTGELU, 1), ("multiply_add_fastgelu", capi.EPI_MULTIPLY_ADD_FASTGELU, 2),
+             ("convert_bf16_rtn", capi.EPI_CONVERT_BF16_RTN, 0)]
+
+
+def preshuffle(b, bits4: bool, K: int, N: int) -> torch.Tensor:
+    stream = torch.cuda.current_stream().cuda_stream
+    if bits4:
+        out = torch.zeros(N * K // 2, dtype=torch.uint8, device="cuda")
+        capi.preshuffle_int4(b.data_ptr(), K // 2, K, N, out.data_ptr(), K, stream)
+    else:
+        src = dev(b)
+        out = torch.zeros(N * K, dtype=torch.int8, device="cuda")
+        capi.preshuffle_int8(src.data_ptr(), K, K, N, out.data_ptr(), K, stream)
+    torch.cuda.synchronize()
+    return out
+
+
+def one_case(rng) -> dict:
+    a_dtype = (capi.F16, capi.BF16)[int(rng.integers(0, 2))]
+    fmt = ("i4", "i8", "u8", "i4pre", "i8pre")[int(rng.integers(0, 5))]
+    M = int(rng.choice([1, 2, 5, 8, 16, 17, 32, 48, 64, 65, 100, 128, 200, 256, 257, 300, 512, 700, 1024, 1500, 2048]))
+    N = int(rng.choice([32, 64, 96, 128, 192, 256, 320, 512, 768, 1024, 1536, 2048, 4096]))
+    K = int(rng.choice([64, 128, 192, 256, 384, 512, 640, 1024, 1536, 2048, 4096]))
+    if fmt in ("i4", "i8", "u8") and rng.integers(0, 6) == 0:   # shapes off the tile grid: N % 4, K % 8 only
+        N += int(rng.choice([4, 20, 100]))
+        K += int(rng.choice([8, 40]))
+    bits4 = fmt.startswith("i4")
+    lo, hi = (-8, 8) if bits4 else (-128, 128)
+    q = rng.integers(lo, hi, (N, K)).astype(np.int8)
+    plain = pack_on_device(q, K, N) if bits4 else q
+    plain_dtype = capi.I4_PACKED if bits4 else capi.I8
+    if fmt == "u8":
+        b, b_dtype = (q.astype(np.int16) + 128).astype(np.uint8), capi.U8_OFFSET
+    elif fmt.endswith("pre"):
+        b, b_dtype = preshuffle(plain, bits4, K, N), (capi.I4_PRESHUFFLED if bits4 else capi.I8_PRESHUFFLED)
+    else:
+        b, b_dtype = plain, plain_dtype
+    cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
+    lda = K + int(rng.choice([0, 0, 8, 64]))
+    a = np.zeros((M, lda), dtype=np.uint16)
+    a[:, :K] = cvt(np.round(rng.uniform(-2, 2, (M, K))))
+    kw = dict(a_dtype=a_dtype, lda=lda)
+    group = int(rng.choice([0, 0, 64, 128, 256]))
+    if group and K % group == 0 and fmt != "u8":
+        s = cvt(rng.integers(1, 3, (K // group, N)).astype(np.float32))
+        kw.update(scale_group_k=group, ld_scale=N)
+    else:
+        group = 0
+        s = cvt(rng.integers(1, 3, N).astype(np.float32))
+    name, epi, nd = EPILOGUES[int(rng.integers(0, len(EPILOGUES)))]
+    if epi == capi.EPI_CONVERT_BF16_RTN and a_dtype != capi.BF16:
+        name, epi, nd = EPILOGUES[0]
+    kw["epilogue"] = epi
+    if nd >= 1:
+        kw["d0"] = cvt(rng.integers(-3, 4, N).astype(np.float32))
+    if nd >= 2:
+        kw["d1"] = cvt(rng.integers(-3, 4, N).astype(np.float32))
+    if rng.integers(0, 2):
+        kw["ldc"] = N + 8
+    ref = run_fpaintb(a, plain, s, M, N, K, b_dtype=plain_dtype, flags=capi.FLAG_GENERIC, expect_kernel="wq_gemm_generic", **kw)
+    flags = 0
+    r = int(rng.integers(0, 6))
+    if r == 0:
+        flags = capi.FLAG_TILE_128
+    elif r == 1:
+        flags = capi.FLAG_TILE_256
+    if rng.integers(0, 4) == 0 and K >= 512:
+        kw["k_batch"] = int(rng.integers(2, 6))
+    elif rng.integers(0, 3) == 0:   # the planner's own split-K is optional: without a workspace it runs one slice
+        kw["use_workspace"] = False
+    # a flag or a split the planner refuses for this shape is dropped, not an error of the sweep
+    probe = capi.fpAintB_problem(1 << 20, 1 << 20, 1 << 20, 1 << 20, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, lda=lda,
+                                 ldc=kw.get("ldc"), epilogue=epi, d0=(1 << 20) if nd >= 1 else None,
+                                 d1=(1 << 20) if nd >= 2 else None, k_batch=kw.get("k_batch", 1), flags=flags,
+                                 scale_group_k=group, ld_scale=N if group else 0)
+    if not capi.is_supported(probe):
+        flags = 0
+        kw.pop("k_batch", None)
+        probe.flags, probe.k_batch = 0, 1
+        if not capi.is_supported(probe):
+            return dict(skipped=capi.lib.wqgemm_last_error().decode(), fmt=fmt, M=M, N=N, K=K)
+    kernel = capi.kernel_name(probe)
+    got = run_fpaintb(a, b, s, M, N, K, b_dtype=b_dtype, flags=flags, **kw)
+    desc = dict(fmt=fmt, a="f16" if a_dtype == capi.F16 else "bf16", M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), group=group,
+                epilogue=name, k_batch=kw.get("k_batch", 1), workspace=kw.get("use_workspace", True), flags=flags, kernel=kernel)
+    # (an output still holding the poison pattern everywhere would compare equal: that is a failure too)
+    desc["equal"] = bool(np.array_equal(got[:, :N], ref[:, :N]) and (got[:, :N] != 0x7BFF).any())
+    desc["padding_untouched"] = bool((got[:, N:] == 0x7BFF).all())
+    if not desc["equal"]:
+        bad = got[:, :N] != ref[:, :N]
+        desc["mismatches"] = int(bad.sum())
+        if bad.any():
+            i, j = np.argwhere(bad)[0]
+            desc["first"] = [int(i), int(j), int(got[i, j]), int(ref[i, j])]
+    return desc
+
+
+def _run_i8(a, b, M, N, K, requant, flags, lda, ldb, ldc, bias, relu):
+    a_t, b_t = dev(a), dev(b)
+    e_t = torch.full((M + 16, ldc), 77, dtype=torch.int8, device="cuda")   # 16 guard rows
+    bias_t = dev(np.ascontiguousarray(bias, np.int32)) if bias is not None else None
+    epi = ((capi.EPI_ADD_RELU_MUL_CLAMP if relu else capi.EPI_ADD_ACT_MUL_CLAMP) if bias is not None
+           else (capi.EPI_RELU_MUL_CLAMP if relu else capi.EPI_ACT_MUL_CLAMP))
+    p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), None, e_t.data_ptr(), M, N, K, a_dtype=capi.I8, b_dtype=capi.I8,
+                             c_dtype=capi.I8, epilogue=epi, requant=requant, d0=bias_t.data_ptr() if bias_t is not None else None,
+                             flags=flags, lda=lda, ldb=ldb, ldc=ldc)
+    if not capi.is_supported(p):
+        return None, None
+    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return e_t.cpu().numpy(), capi.kernel_name(p)
+
+
+def one_case_i8(rng) -> dict:
+    """int8 x int8 -> int8 behind the requantisation epilogues: integer accumulation, so random data is exact."""
+    M = int(rng.choice([1, 5, 16, 64, 100, 128, 200, 256, 300, 513, 1024, 2048]))
+    N = int(rng.choice([16, 100, 128, 256, 384, 512, 1024, 2048, 4096]))
+    K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 4096]))
+    lda, ldb, ldc = K + int(rng.choice([0, 0, 16, 128])), K + int(rng.choice([0, 0, 16, 128])), N + int(rng.choice([0, 0, 16]))
+    a = rng.integers(-128, 128, (M, lda)).astype(np.int8)
+    b = rng.integers(-128, 128, (N, ldb)).astype(np.int8)
+    bias = rng.integers(-50000, 50001, N).astype(np.int32) if rng.integers(0, 2) else None
+    relu = bool(rng.integers(0, 2))
+    rq = float(rng.choice([1e-4, 1e-3, 0.03]))
+    flags = (0, capi.FLAG_TILE_128, capi.FLAG_TILE_256)[int(rng.integers(0, 3))]
+    got, kernel = _run_i8(a, b, M, N, K, rq, flags, lda, ldb, ldc, bias, relu)
+    if got is None:
+        got, kernel = _run_i8(a, b, M, N, K, rq, 0, lda, ldb, ldc, bias, relu)
+    ref, _ = _run_i8(a, b, M, N, K, rq, capi.FLAG_GENERIC, lda, ldb, ldc, bias, relu)
+    desc = dict(fmt="i8xi8", M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, bias=bias is not None, relu=relu, requant=rq, k_batch=1,
+                kernel=kernel)
+    desc["equal"] = bool(np.array_equal(got[:M, :N], ref[:M, :N]) and (got[:M, :N] != 77).any())
+    desc["padding_untouched"] = bool((got[M:] == 77).all() and (got[:, N:] == 77).all())
+    return desc
+
+
+E4M3FNUZ = {0: 0x00, 1: 0x40, 2: 0x48, 3: 0x4C, 4: 0x50, -1: 0xC0, -2: 0xC8, -3: 0xCC, -4: 0xD0}   # bias 8
+E4M3FN = {0: 0x00, 1: 0x38, 2: 0x40, 3: 0x44, 4: 0x48, -1: 0xB8, -2: 0xC0, -3: 0xC4, -4: 0xC8}     # bias 7
+
+
+def one_case_f8(rng) -> dict:
+    """fp8 x int4 + MultiplyMultiply[+FastGelu] on the fp8 matrix core, both byte formats, plain and pre-shuffled
+    weights: small integers as activations and power-of-two factors keep every sum exact."""
+    M = int(rng.choice([65, 100, 128, 256, 300, 512, 700, 1024, 2048]))
+    N = int(rng.choice([256, 512, 1024, 2048, 4096]))
+    K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 4096]))
+    fn = bool(rng.integers(0, 2))
+    pre = bool(rng.integers(0, 2))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    plain = pack_on_device(q, K, N)
+    b = preshuffle(plain, True, K, N) if pre else plain
+    lda = K + int(rng.choice([0, 0, 16, 128]))
+    lut = np.zeros(9, dtype=np.uint8)
+    for v, code in (E4M3FN if fn else E4M3FNUZ).items():
+        lut[v + 4] = code
+    a = np.zeros((M, lda), dtype=np.uint8)
+    a[:, :K] = lut[rng.integers(-4, 5, (M, K)) + 4]
+    d0 = (2.0 ** rng.integers(-6, -2, N)).astype(np.float32)
+    d1 = (2.0 ** rng.integers(-3, 1, M)).astype(np.float32)
+    gelu = bool(rng.integers(0, 2))
+    kw = dict(a_dtype=capi.F8_E4M3FN if fn else capi.F8_FNUZ, lda=lda, d0=d0, d1=d1,
+              epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU if gelu else capi.EPI_MULTIPLY_MULTIPLY)
+    if rng.integers(0, 2):
+        kw["ldc"] = N + 8
+    kb = int(rng.integers(2, 6)) if (rng.integers(0, 4) == 0 and K >= 512) else 1
+    flags = 0 if fn else capi.FLAG_F8_NO_SPECIALS
+    if not pre and rng.integers(0, 4) == 0:
+        flags |= capi.FLAG_PINGPONG
+    ref = run_fpaintb(a, plain, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel="wq_gemm_generic", **kw)
+    got = run_fpaintb(a, b, None, M, N, K, b_dtype=capi.I4_PRESHUFFLED if pre else capi.I4_PACKED, flags=flags, k_batch=kb,
+                      expect_kernel="wq_gemm_f8_mfma_256", **kw)
+    desc = dict(fmt="f8xi4" + ("pre" if pre else ""), e4m3fn=fn, M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), gelu=gelu, k_batch=kb,
+                flags=flags, kernel="wq_gemm_f8_mfma_256")
+    # (an output still holding the poison pattern everywhere would compare equal: that is a failure too)
+    desc["equal"] = bool(np.array_equal(got[:, :N], ref[:, :N]) and (got[:, :N] != 0x7BFF).any())
+    desc["padding_untouched"] = bool((got[:, N:] == 0x7BFF).all())
+    if not desc["equal"]:
+        bad = got[:, :N] != ref[:, :N]
+        desc["mismatches"] = int(bad.sum())
+        if bad.any():
+            i, j = np.argwhere(bad)[0]
+            desc["first"] = [int(i), int(j), int(got[i, j]), int(ref[i, j])]
+    return desc
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--family", choices=("fp", "i8", "f8"), default="fp",
+                    help="fp: fp16/bf16 x int4/int8; i8: int8 x int8 requantised; f8: fp8 x int4 MultiplyMultiply")
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    kernels, failures, skipped, n = {}, [], 0, 0
+    while time.time() - t0 < args.seconds:
+        d = {"fp": one_case, "i8": one_case_i8, "f8": one_case_f8}[args.family](rng)
+        if "skipped" in d:
+            skipped += 1
+            continue
+        n += 1
+        key = d["kernel"] + ("" if d["k_batch"] == 1 else "+splitk")
+        kernels[key] = kernels.get(key, 0) + 1
+        if not (d["equal"] and d["padding_untouched"]):
+            failures.append(d)
+            print("FAIL", json.dumps(d), flush=True)
+        if n % 50 == 0:
+            print(f"[{time.time() - t0:6.0f} s] {n} cases, {len(failures)} failures, {skipped} skipped", flush=True)
+    summary = dict(family=args.family, seed=args.seed, seconds=round(time.time() - t0, 1), cases=n, skipped=skipped, failures=failures, kernels=kernels)
+    print(json.dumps(summary))
+    if args.out:
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(summary, f, indent=1)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
