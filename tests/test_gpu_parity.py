@@ -1592,6 +1592,25 @@ def test_random_shapes_f8_int4_against_the_general_kernel():
         np.testing.assert_array_equal(got, ref, err_msg=f"case {case}: M={M} N={N} K={K} e4m3fn={fn}")
 
 
+def test_f8_int4_caller_split_k_in_128_deep_slices():
+    """A caller's k_batch that does not divide K into whole 128-k tiles evenly (2048 / 3, / 5, / 7): the slices are cut in
+    the fp8 kernel's tiles, trailing ones shorter or empty, and the sum equals the general kernel's single pass bit for
+    bit on exact inputs."""
+    rng = np.random.default_rng(651)
+    lut_fn = {0: 0x00, 1: 0x38, 2: 0x40, -1: 0xB8, -2: 0xC0}     # OCP E4M3FN (bias 7)
+    M, N, K = 300, 512, 2048
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    a = np.vectorize(lut_fn.get)(rng.integers(-2, 3, (M, K))).astype(np.uint8)
+    d0 = (2.0 ** rng.integers(-6, -2, N)).astype(np.float32)
+    d1 = (2.0 ** rng.integers(-3, 1, M)).astype(np.float32)
+    kw = dict(a_dtype=capi.F8_E4M3FN, epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU, d0=d0, d1=d1)
+    ref = run_fpaintb(a, bp, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC, **kw)
+    for kb in (3, 5, 7, 17):
+        got = run_fpaintb(a, bp, None, M, N, K, k_batch=kb, expect_kernel=F8_MFMA, **kw)
+        np.testing.assert_array_equal(got, ref, err_msg=f"k_batch = {kb}")
+
+
 def test_torch_linear_preshuffled_weights(tmp_path):
     """Pre-shuffled int4 weights through the container and the torch operator: the same bits as the packed layout of
     the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch and for an N that only the
