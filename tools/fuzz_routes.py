@@ -29,7 +29,9 @@ from gpu_util import bf16_bits, dev, f16_bits, pack_on_device, run_fpaintb  # no
 EPILOGUES = [("passthrough", capi.EPI_PASSTHROUGH, 0), ("fastgelu", capi.EPI_FASTGELU, 0), ("add", capi.EPI_ADD, 1),
              ("add_fastgelu", capi.EPI_ADD_FASTGELU, 1), ("multiply", capi.EPI_MULTIPLY, 1),
              ("multiply_fastgelu", capi.EPI_MULTIPLY_FASTGELU, 1), ("multiply_add_fastgelu", capi.EPI_MULTIPLY_ADD_FASTGELU, 2),
-             ("convert_bf16_rtn", capi.EPI_CONVERT_BF16_RTN, 0)]
+             ("convert_bf16_rtn", capi.EPI_CONVERT_BF16_RTN, 0), ("multiply_add_bits", capi.EPI_MULTIPLY_ADD, 2)]
+VARIANTS = [capi.FLAG_LOCKSTEP, capi.FLAG_WAVES_2X4, capi.FLAG_DEQUANT_IN_L, capi.FLAG_DIRECT_STORE, capi.FLAG_GROUP8,
+            capi.FLAG_MFMA_32X32]
 
 
 def preshuffle(b, bits4: bool, K: int, N: int) -> torch.Tensor:
@@ -59,12 +61,28 @@ def one_case(rng) -> dict:
     q = rng.integers(lo, hi, (N, K)).astype(np.int8)
     plain = pack_on_device(q, K, N) if bits4 else q
     plain_dtype = capi.I4_PACKED if bits4 else capi.I8
+    bkw = {}   # leading dimension / layout of the weights under test
     if fmt == "u8":
         b, b_dtype = (q.astype(np.int16) + 128).astype(np.uint8), capi.U8_OFFSET
     elif fmt.endswith("pre"):
         b, b_dtype = preshuffle(plain, bits4, K, N), (capi.I4_PRESHUFFLED if bits4 else capi.I8_PRESHUFFLED)
     else:
         b, b_dtype = plain, plain_dtype
+    if fmt in ("i8", "u8") and rng.integers(0, 5) == 0:      # row-major (K, N) weights
+        ldb = N + int(rng.choice([0, 16]))
+        bt = np.zeros((K, ldb), dtype=b.dtype)
+        bt[:, :N] = b.T
+        b, bkw = bt, dict(b_layout=capi.ROW_MAJOR, ldb=ldb)
+    elif fmt in ("i8", "u8") and rng.integers(0, 3) == 0:    # padded columns
+        ldb = K + int(rng.choice([16, 64]))
+        bp = np.zeros((N, ldb), dtype=b.dtype)
+        bp[:, :K] = b
+        b, bkw = bp, dict(ldb=ldb)
+    elif fmt == "i4" and rng.integers(0, 3) == 0:
+        ldb = K + int(rng.choice([32, 64]))
+        bp = torch.zeros((N, ldb // 2), dtype=torch.uint8, device="cuda")
+        bp[:, :K // 2] = plain
+        b, bkw = bp, dict(ldb=ldb)
     cvt = f16_bits if a_dtype == capi.F16 else bf16_bits
     lda = K + int(rng.choice([0, 0, 8, 64]))
     a = np.zeros((M, lda), dtype=np.uint16)
@@ -72,19 +90,31 @@ def one_case(rng) -> dict:
     kw = dict(a_dtype=a_dtype, lda=lda)
     group = int(rng.choice([0, 0, 64, 128, 256]))
     if group and K % group == 0 and fmt != "u8":
-        s = cvt(rng.integers(1, 3, (K // group, N)).astype(np.float32))
-        kw.update(scale_group_k=group, ld_scale=N)
+        ld_scale = N + int(rng.choice([0, 0, 8]))
+        s = np.zeros((K // group, ld_scale), dtype=np.uint16)
+        s[:, :N] = cvt(rng.integers(1, 3, (K // group, N)).astype(np.float32))
+        kw.update(scale_group_k=group, ld_scale=ld_scale)
     else:
         group = 0
         s = cvt(rng.integers(1, 3, N).astype(np.float32))
     name, epi, nd = EPILOGUES[int(rng.integers(0, len(EPILOGUES)))]
-    if epi == capi.EPI_CONVERT_BF16_RTN and a_dtype != capi.BF16:
+    if epi in (capi.EPI_CONVERT_BF16_RTN, capi.EPI_MULTIPLY_ADD) and a_dtype != capi.BF16:
         name, epi, nd = EPILOGUES[0]
     kw["epilogue"] = epi
+    full_d = nd >= 1 and rng.integers(0, 4) == 0   # full (M, N) D tensors instead of per-column vectors
+    ldd = N + int(rng.choice([0, 8])) if full_d else 0
+
+    def d_operand():
+        if not full_d:
+            return cvt(rng.integers(-3, 4, N).astype(np.float32))
+        d = np.zeros((M, ldd), dtype=np.uint16)
+        d[:, :N] = cvt(rng.integers(-3, 4, (M, N)).astype(np.float32))
+        return d
+
     if nd >= 1:
-        kw["d0"] = cvt(rng.integers(-3, 4, N).astype(np.float32))
+        kw.update(d0=d_operand(), ldd0=ldd)
     if nd >= 2:
-        kw["d1"] = cvt(rng.integers(-3, 4, N).astype(np.float32))
+        kw.update(d1=d_operand(), ldd1=ldd)
     if rng.integers(0, 2):
         kw["ldc"] = N + 8
     ref = run_fpaintb(a, plain, s, M, N, K, b_dtype=plain_dtype, flags=capi.FLAG_GENERIC, expect_kernel="wq_gemm_generic", **kw)
@@ -94,6 +124,8 @@ def one_case(rng) -> dict:
         flags = capi.FLAG_TILE_128
     elif r == 1:
         flags = capi.FLAG_TILE_256
+        if rng.integers(0, 2):
+            flags |= VARIANTS[int(rng.integers(0, len(VARIANTS)))]
     if rng.integers(0, 4) == 0 and K >= 512:
         kw["k_batch"] = int(rng.integers(2, 6))
     elif rng.integers(0, 3) == 0:   # the planner's own split-K is optional: without a workspace it runs one slice
@@ -102,7 +134,8 @@ def one_case(rng) -> dict:
     probe = capi.fpAintB_problem(1 << 20, 1 << 20, 1 << 20, 1 << 20, M, N, K, a_dtype=a_dtype, b_dtype=b_dtype, lda=lda,
                                  ldc=kw.get("ldc"), epilogue=epi, d0=(1 << 20) if nd >= 1 else None,
                                  d1=(1 << 20) if nd >= 2 else None, k_batch=kw.get("k_batch", 1), flags=flags,
-                                 scale_group_k=group, ld_scale=N if group else 0)
+                                 scale_group_k=group, ld_scale=kw.get("ld_scale", 0), ldd0=kw.get("ldd0", 0), ldd1=kw.get("ldd1", 0),
+                                 **bkw)
     if not capi.is_supported(probe):
         flags = 0
         kw.pop("k_batch", None)
@@ -110,8 +143,8 @@ def one_case(rng) -> dict:
         if not capi.is_supported(probe):
             return dict(skipped=capi.lib.wqgemm_last_error().decode(), fmt=fmt, M=M, N=N, K=K)
     kernel = capi.kernel_name(probe)
-    got = run_fpaintb(a, b, s, M, N, K, b_dtype=b_dtype, flags=flags, **kw)
-    desc = dict(fmt=fmt, a="f16" if a_dtype == capi.F16 else "bf16", M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), group=group,
+    got = run_fpaintb(a, b, s, M, N, K, b_dtype=b_dtype, flags=flags, **bkw, **kw)
+    desc = dict(weights=bkw, full_d=bool(full_d), fmt=fmt, a="f16" if a_dtype == capi.F16 else "bf16", M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), group=group,
                 epilogue=name, k_batch=kw.get("k_batch", 1), workspace=kw.get("use_workspace", True), flags=flags, kernel=kernel)
     # (an output still holding the poison pattern everywhere would compare equal: that is a failure too)
     desc["equal"] = bool(np.array_equal(got[:, :N], ref[:, :N]) and (got[:, :N] != 0x7BFF).any())
