@@ -80,6 +80,7 @@ struct Plan
     bool partial  = false; // main kernel writes fp32 partial slabs
     bool to_c     = false; // ... directly into p->c (multi-GPU slice) instead of the workspace
     bool auto_split = false; // split-K chosen by the planner (small-M kernel, short grids of the 128-tile kernel): needs, and is dropped without, a workspace
+    bool split_256  = false; // the planner's split-K is what put this problem on the 256-tile kernel
     bool via_colb = false; // row-major 8-bit B: transpose into the workspace, then the K-contiguous matrix-core kernels
     bool via_f16  = false; // fp8 FNUZ activations: convert to fp16 in the workspace, then the fp16 MFMA kernel
 };
@@ -368,6 +369,32 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         const long wgs = (long)((p->M + 255) / 256) * (p->N / 256) * plan.k_batch;
         if(wgs >= 128 || (p->flags & WQ_FLAG_TILE_256))
             plan.route = ROUTE_MFMA256;
+        // Between 40 (32 once K reaches 8192) and 128 tiles (M of a few hundred rows against a few thousand columns) the 256-tile kernel still
+        // wins once K is split across blockIdx.z up to one workgroup per CU, in slices of at least 768 k: 10 - 40 % over
+        // the 128-tile kernel's best split at M = 192 ... 2048 against 4096 ... 28672 columns (tools/mid_m_sweep.py).
+        // Planner's own split: needs a workspace, and without one the launch goes back to the 128-tile kernel.
+        const int klen = plan.k_end - plan.k_begin;
+        if(wgs >= (klen >= 8192 ? 32 : 40) && wgs <= 128 && !plan.partial && !plan.via_f16 && !plan.via_colb && p->M > 128 &&
+           !(p->flags & (WQ_FLAG_TILE_256 | WQ_FLAG_MFMA_32X32)))
+        {
+            int kb = (int)(256 / wgs);
+            if(kb > klen / 768)
+                kb = klen / 768;
+            if(kb > 1)
+            {
+                const int per = wqgemm_splitk_kread(klen, kb, 64);
+                kb            = (klen + per - 1) / per;
+                if(kb > 1)
+                {
+                    plan.route      = ROUTE_MFMA256;
+                    plan.auto_split = true;
+                    plan.split_256  = wgs < 128;
+                    plan.k_batch    = kb;
+                    plan.k_per_z    = per;
+                    plan.partial    = true;
+                }
+            }
+        }
     }
     // Few tiles (a short M against a narrow N) leave most CUs idle: split K across blockIdx.z when the caller has not,
     // up to about one workgroup per CU and at least four K tiles per slice.  Needs (and is dropped without) a workspace.
@@ -377,9 +404,25 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         const int klen = plan.k_end - plan.k_begin;
         // (up to 128 workgroups: about one per CU after the split; up to two per CU, which the 128-tile kernel runs
         // side by side, halves of a long K still pay: measured 15 - 20 % at 4096 <= K)
-        int kb         = wgs <= 128 ? 256 / wgs : (wgs < 512 && klen >= 4096 ? 2 : 1);
-        if(kb > klen / 256)
-            kb = klen / 256;
+        int kb = wgs < 512 && klen >= 4096 ? 2 : 1;
+        if(wgs <= 128)
+        {
+            // The busiest CU runs ceil(wgs * kb / 256) workgroups of klen / kb each: pick the kb with the shortest such
+            // chain, a second workgroup per CU (slices of at least 1024 k then, 256 k otherwise) counting as a tenth
+            // faster than its share; ties go to the smaller kb (less partial traffic).  Workgroup counts between 256
+            // and 512 that are not near 512 lose: 320 workgroups run as long as 512 of the same slice length.
+            int best_score = 0;
+            kb             = 1;
+            for(int c = 1; c <= 16 && wgs * c <= 512; ++c)
+            {
+                const int chain = (wgs * c + 255) / 256;
+                if(klen / c < (chain > 1 ? 1024 : 256))
+                    break;
+                const int score = 1000 * c / chain * (chain > 1 ? 11 : 10);
+                if(score > best_score)
+                    best_score = score, kb = c;
+            }
+        }
         if(kb > 1)
         {
             const int per = wqgemm_splitk_kread(klen, kb, 64);
@@ -804,6 +847,8 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
         plan.k_batch    = 1;
         plan.partial    = false;
         plan.k_per_z    = plan.k_end - plan.k_begin;
+        if(plan.split_256) // too few 256-tiles for one slice each: the 128-tile kernel's grid is four times as long
+            plan.route = ROUTE_MFMA128;
     }
     if(plan.partial && !plan.to_c && !workspace)
         return fail(WQ_ERR_WORKSPACE, "k_batch = %d needs a workspace of %zu bytes", plan.k_batch,

@@ -352,3 +352,23 @@ def test_caller_split_k_of_fp8_activations_stays_on_the_fp8_kernel():
             for b_dtype in (capi.I4_PACKED, capi.I4_PRESHUFFLED):
                 p = _problem(K=K, lda=K, ldb=K, k_batch=kb, b_dtype=b_dtype, **f8)
                 assert capi.kernel_name(p) == "wq_gemm_f8_mfma_256", (K, kb)
+
+
+def test_planner_split_k_puts_mid_sized_m_on_the_256_tile_kernel():
+    """A few hundred rows against a few thousand columns: too few 256-tiles for one per CU, so the planner splits K
+    (optional workspace) up to about one workgroup per CU instead of falling back to 128-tiles."""
+    p = _problem(M=768)                                    # 3 x 16 = 48 tiles -> 5 slices
+    assert capi.kernel_name(p) == "wq_gemm_mfma_256" and "KBatch5" in capi.type_string(p)
+    assert capi.workspace_bytes(p) == 5 * 768 * 4096 * 4
+    p = _problem(M=1536)                                   # 96 tiles -> 2 slices
+    assert capi.kernel_name(p) == "wq_gemm_mfma_256" and "KBatch2" in capi.type_string(p)
+    p = _problem(M=512)                                    # 32 tiles at K = 4096: the 128-tile kernel, two workgroups per CU
+    assert capi.kernel_name(p) == "wq_gemm_mfma_128" and "KBatch4" in capi.type_string(p)
+    p = _problem(M=512, K=8192, lda=8192, ldb=8192)        # ... but the 256-tile kernel once K is long
+    assert capi.kernel_name(p) == "wq_gemm_mfma_256" and "KBatch8" in capi.type_string(p)
+    p = _problem(M=128, N=11008)                           # at most 128 rows stay on 128-tiles
+    assert capi.kernel_name(p) == "wq_gemm_mfma_128"
+    p = _problem(M=768, K=1024, lda=1024, ldb=1024)        # slices would be shorter than 768 k: no split, 128-tiles
+    assert capi.kernel_name(p) == "wq_gemm_mfma_128"
+    p = _problem(M=768, k_batch=2)                         # the caller's own split is left as it is
+    assert capi.kernel_name(p) == "wq_gemm_mfma_128" and "KBatch2" in capi.type_string(p)

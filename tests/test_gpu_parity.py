@@ -1611,6 +1611,32 @@ def test_f8_int4_caller_split_k_in_128_deep_slices():
         np.testing.assert_array_equal(got, ref, err_msg=f"k_batch = {kb}")
 
 
+@pytest.mark.parametrize("b_dtype", [capi.I4_PACKED, capi.I4_PRESHUFFLED])
+def test_planner_split_k_on_the_256_tile_kernel(port, b_dtype):
+    """M = 768 against 4096 columns: 48 tiles of 256 x 256, which the planner runs as five K slices on the 256-tile
+    kernel when it gets a workspace and on the 128-tile kernel when it does not.  Exact inputs: both equal the general
+    kernel bit for bit; realistic inputs: a row block of each against the CPU checker."""
+    rng = np.random.default_rng(768)
+    M, N, K = 768, 4096, 4096
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    packed = pack_on_device(q, K, N)
+    b = packed if b_dtype == capi.I4_PACKED else preshuffle_on_device(packed, K, N)
+    ai = f16_bits(np.round(rng.uniform(-2, 2, (M, K))))
+    si = f16_bits(rng.integers(1, 3, N).astype(np.float32))
+    with_ws = run_fpaintb(ai, b, si, M, N, K, b_dtype=b_dtype, expect_kernel=MFMA256)
+    without = run_fpaintb(ai, b, si, M, N, K, b_dtype=b_dtype, use_workspace=False)
+    gen = run_fpaintb(ai, packed, si, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC)
+    np.testing.assert_array_equal(with_ws, gen)
+    np.testing.assert_array_equal(without, gen)
+    a = f16_bits(rng.uniform(-1, 1, (M, K)))
+    s = f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N))
+    rows = slice(700, 732)
+    exp = port.fpAintB_gemm_f16(np.ascontiguousarray(a[rows]), q, s, 32, N, K, K, K, N).reshape(32, N)
+    for use_ws in (True, False):
+        got = run_fpaintb(a, b, s, M, N, K, b_dtype=b_dtype, use_workspace=use_ws)
+        check_err(bits_to_f32(got[rows], capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
 def test_torch_linear_preshuffled_weights(tmp_path):
     """Pre-shuffled int4 weights through the container and the torch operator: the same bits as the packed layout of
     the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch and for an N that only the
