@@ -341,11 +341,47 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                                                           : (((uint64_t)p->K - 1) * (uint64_t)p->ldb + (uint64_t)p->N) / b_div;
     const bool fits_32bit = a_span * (is_f8 || p->a_dtype == WQ_I8 ? 1 : 2) <= 0x7FFFFFFFull && b_span <= 0x7FFFFFFFull;
     if(is_f8 && fits_32bit && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
-       is_i4(p->b_dtype) && !(preshuf && (p->flags & WQ_FLAG_PINGPONG)) && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->M > 64 && p->N % 256 == 0 &&
+       is_i4(p->b_dtype) && !(preshuf && (p->flags & WQ_FLAG_PINGPONG)) && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->N % 256 == 0 &&
        plan.k_begin % 128 == 0 && plan.k_per_z % 128 == 0 && (plan.k_end - plan.k_begin) % 128 == 0 &&
        p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
        (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
+    {
         plan.route = ROUTE_F8_MFMA256;
+        // A grid shorter than the chip (M up to a thousand rows or so): split K across blockIdx.z when the caller has
+        // not.  Needs (and is dropped without) a workspace.  The slice count minimises a cost model in microseconds
+        // fitted to tools/mid_m_sweep.py --f8 (within 10 % of the best measured candidate at all 55 points, 0.5 % on
+        // average): per workgroup a fixed 10 us (prologue, epilogue) plus 0.9 - 1.4 us per 128-k tile depending on how
+        // much of the chip is busy, times the number of workgroups the busiest CU runs; the fp32 partials cost their
+        // 8 bytes per slice and output at 8 TB/s (they mostly stay in the last-level cache) plus 3 us for the reduction.
+        const int tiles = ((p->M + 255) / 256) * (p->N / 256);
+        const int klen  = plan.k_end - plan.k_begin;
+        if(!plan.partial && tiles < 256)
+        {
+            double best = 1e30;
+            int kb      = 1;
+            for(int c = 1; c <= 8 && (c == 1 || klen / c >= 512); ++c)
+            {
+                const int wgs = tiles * c, chain = (wgs + 255) / 256, kt = (klen / c + 127) / 128;
+                double t = chain * (10.0 + kt * (0.9 + 0.5 * std::min(1.0, wgs / 256.0)));
+                if(c > 1)
+                    t += (double)c * p->M * p->N * 8.0 / 8e6 + 3.0;
+                if(t < best)
+                    best = t, kb = c;
+            }
+            if(kb > 1)
+            {
+                const int per = wqgemm_splitk_kread(klen, kb, 128);
+                kb            = (klen + per - 1) / per;
+                if(kb > 1)
+                {
+                    plan.auto_split = true;
+                    plan.k_batch    = kb;
+                    plan.k_per_z    = per;
+                    plan.partial    = true;
+                }
+            }
+        }
+    }
     // FNUZ bytes without that promise: exact in every encoding through an fp16 image of A in the workspace and
     // the fp16 kernels with a unit weight scale (falls back to the general kernel when no workspace is given).
     if(p->a_dtype == WQ_F8_FNUZ && plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) &&

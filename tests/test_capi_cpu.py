@@ -372,3 +372,17 @@ def test_planner_split_k_puts_mid_sized_m_on_the_256_tile_kernel():
     assert capi.kernel_name(p) == "wq_gemm_mfma_128"
     p = _problem(M=768, k_batch=2)                         # the caller's own split is left as it is
     assert capi.kernel_name(p) == "wq_gemm_mfma_128" and "KBatch2" in capi.type_string(p)
+
+
+def test_fp8_activations_short_grids_split_k_and_small_m():
+    """fp8 activations: every M runs on the fp8 matrix-core kernel (no general-kernel fallback for decode-sized
+    batches), and a grid shorter than the chip gets the planner's own K split (optional workspace)."""
+    f8 = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, scale=None, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=0x10000, d1=0x10000)
+    for M in (1, 16, 64, 65, 512):
+        p = _problem(M=M, **f8)
+        assert capi.kernel_name(p) == "wq_gemm_f8_mfma_256"
+        assert "KBatch" in capi.type_string(p) and "KBatch1>" not in capi.type_string(p), capi.type_string(p)
+        assert capi.workspace_bytes(p) > 0
+    for M in (2048, 4096):                                # half the chip and more: one slice
+        p = _problem(M=M, **f8)
+        assert "KBatch1>" in capi.type_string(p) and capi.workspace_bytes(p) == 0

@@ -204,7 +204,7 @@ E4M3FN = {0: 0x00, 1: 0x38, 2: 0x40, 3: 0x44, 4: 0x48, -1: 0xB8, -2: 0xC0, -3: 0
 def one_case_f8(rng) -> dict:
     """fp8 x int4 + MultiplyMultiply[+FastGelu] on the fp8 matrix core, both byte formats, plain and pre-shuffled
     weights: small integers as activations and power-of-two factors keep every sum exact."""
-    M = int(rng.choice([65, 100, 128, 256, 300, 512, 700, 1024, 2048]))
+    M = int(rng.choice([1, 7, 16, 64, 65, 100, 128, 256, 300, 512, 700, 1024, 2048]))
     N = int(rng.choice([256, 512, 1024, 2048, 4096]))
     K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 4096]))
     fn = bool(rng.integers(0, 2))
@@ -231,7 +231,7 @@ def one_case_f8(rng) -> dict:
         flags |= capi.FLAG_PINGPONG
     ref = run_fpaintb(a, plain, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel="wq_gemm_generic", **kw)
     got = run_fpaintb(a, b, None, M, N, K, b_dtype=capi.I4_PRESHUFFLED if pre else capi.I4_PACKED, flags=flags, k_batch=kb,
-                      expect_kernel="wq_gemm_f8_mfma_256", **kw)
+                      expect_kernel="wq_gemm_f8_mfma_256", use_workspace=bool(kb > 1 or rng.integers(0, 3)), **kw)
     desc = dict(fmt="f8xi4" + ("pre" if pre else ""), e4m3fn=fn, M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), gelu=gelu, k_batch=kb,
                 flags=flags, kernel="wq_gemm_f8_mfma_256")
     # (an output still holding the poison pattern everywhere would compare equal: that is a failure too)

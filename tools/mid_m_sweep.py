@@ -14,6 +14,7 @@ from composable_kernel_amd import capi
 ap = argparse.ArgumentParser()
 ap.add_argument("--pre", action="store_true", help="pre-shuffled weights")
 ap.add_argument("--b", choices=("i4", "i8"), default="i4")
+ap.add_argument("--f8", action="store_true", help="fp8 (E4M3FN) activations, MultiplyMultiply epilogue: the fp8 matrix-core kernel")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -23,13 +24,22 @@ b_dtype = (capi.I4_PRESHUFFLED if args.pre else capi.I4_PACKED) if bits4 else (c
 for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (8192, 8192), (28672, 8192)):
     w = torch.randint(0, 256, (N, K // 2 if bits4 else K), generator=g, device=dev, dtype=torch.uint8)   # timing only: any bytes
     s = (torch.rand((N,), generator=g, device=dev) * 0.01 + 0.001).half()
-    for M in (96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072):
+    for M in ((1, 16, 64) if args.f8 else ()) + (96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072):
         a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).half()
+        if args.f8:
+            a = torch.randint(0, 120, (M, K), generator=g, device=dev, dtype=torch.uint8)   # E4M3FN bytes below NaN
+            d0 = torch.rand((N,), generator=g, device=dev)
+            d1 = torch.rand((M,), generator=g, device=dev)
         c = torch.empty((M, N), dtype=torch.float16, device=dev)
 
         def timed(flags, kb):
-            p = capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K, b_dtype=b_dtype,
-                                     k_batch=kb, flags=flags)
+            if args.f8:
+                p = capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_E4M3FN,
+                                         c_dtype=capi.F16, b_dtype=b_dtype, k_batch=kb, flags=flags,
+                                         epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0.data_ptr(), d1=d1.data_ptr())
+            else:
+                p = capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K, b_dtype=b_dtype,
+                                         k_batch=kb, flags=flags)
             if not capi.is_supported(p):
                 return None, None
             nb = capi.workspace_bytes(p)
@@ -48,7 +58,7 @@ for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (8192, 8192), (28672,
 
         planner_us, planner_ts = timed(0, 1)
         cands = {}
-        for tname, flag in (("t128", capi.FLAG_TILE_128), ("t256", capi.FLAG_TILE_256)):
+        for tname, flag in ((("f8", 0),) if args.f8 else (("t128", capi.FLAG_TILE_128), ("t256", capi.FLAG_TILE_256))):
             for kb in (1, 2, 3, 4, 6, 8):
                 if K // kb < 512:
                     continue
