@@ -189,9 +189,12 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
                               p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 &&
                               (uintptr_t)p->c % 4 == 0 && !(p->flags & WQ_FLAG_GENERIC);
         plan.route = tiled_i8 ? ROUTE_I8_MFMA128 : ROUTE_GENERIC;
-        // 256 x 256 tiles once they cover at least half the chip (and on request)
+        // 256 x 256 tiles once they cover at least half the chip and the 128-tiles no longer fit one round of two
+        // workgroups per CU (up to 512 of them the 128-tile kernel is 5 - 20 % faster: tools/mid_m_sweep.py --i8a), and
+        // on request
+        const long wgs128 = (long)((p->M + 127) / 128) * ((p->N + 127) / 128);
         if(tiled_i8 && p->N % 256 == 0 && p->ldc % 16 == 0 && (uintptr_t)p->c % 16 == 0 && !(p->flags & WQ_FLAG_TILE_128) &&
-           ((long)((p->M + 255) / 256) * (p->N / 256) >= 128 || (p->flags & WQ_FLAG_TILE_256)))
+           (((long)((p->M + 255) / 256) * (p->N / 256) >= 128 && wgs128 > 512) || (p->flags & WQ_FLAG_TILE_256)))
             plan.route = ROUTE_I8_MFMA256;
         if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_I8_MFMA256)
             return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs N to be a multiple of 256 and tile-aligned operands");

@@ -14,12 +14,13 @@ from composable_kernel_amd import capi
 ap = argparse.ArgumentParser()
 ap.add_argument("--pre", action="store_true", help="pre-shuffled weights")
 ap.add_argument("--b", choices=("i4", "i8"), default="i4")
+ap.add_argument("--i8a", action="store_true", help="int8 activations x int8 weights, requantised int8 output (no split-K form)")
 ap.add_argument("--f8", action="store_true", help="fp8 (E4M3FN) activations, MultiplyMultiply epilogue: the fp8 matrix-core kernel")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 stream = torch.cuda.current_stream(); sp = stream.cuda_stream
-bits4 = args.b == "i4"
+bits4 = args.b == "i4" and not args.i8a
 b_dtype = (capi.I4_PRESHUFFLED if args.pre else capi.I4_PACKED) if bits4 else (capi.I8_PRESHUFFLED if args.pre else capi.I8)
 for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (8192, 8192), (28672, 8192)):
     w = torch.randint(0, 256, (N, K // 2 if bits4 else K), generator=g, device=dev, dtype=torch.uint8)   # timing only: any bytes
@@ -31,9 +32,16 @@ for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (8192, 8192), (28672,
             d0 = torch.rand((N,), generator=g, device=dev)
             d1 = torch.rand((M,), generator=g, device=dev)
         c = torch.empty((M, N), dtype=torch.float16, device=dev)
+        if args.i8a:
+            a = torch.randint(-128, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
 
         def timed(flags, kb):
-            if args.f8:
+            if args.i8a:
+                if kb != 1:
+                    return None, None
+                p = capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.I8, b_dtype=capi.I8,
+                                         c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=0.01, flags=flags)
+            elif args.f8:
                 p = capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_E4M3FN,
                                          c_dtype=capi.F16, b_dtype=b_dtype, k_batch=kb, flags=flags,
                                          epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0.data_ptr(), d1=d1.data_ptr())
