@@ -539,6 +539,10 @@ struct I8GemmParams
     float requant;
     int kind;            // wq_epilogue of the requantisation family (5, 10, 11, 12)
     const int32_t* bias; // N values for kinds 11 and 12
+    int32_t* partial;    // non-null (128-tile kernel): blockIdx.z multiplies K tiles [z * k_tiles_per_z, ...) and stores its raw
+                         // int32 accumulators to slab z of this buffer, rows of N values; the requantisation follows
+                         // in wq_reduce_requant_i8
+    int k_tiles_per_z;
 };
 
 #ifdef WQ_MAIN_TU // the non-template kernels below are emitted by wqgemm.hip only
@@ -565,7 +569,9 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
     tile_coords(xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     const int m0 = tm * 128, n0 = tn * 128;
     const int wm = wave & 1, wn = wave >> 1;
-    const int ntiles = p.K / 128;
+    // K tiles of this workgroup: all of them, or slice blockIdx.z (trailing slices may be empty: zero partials)
+    const int kt0    = p.partial ? blockIdx.z * p.k_tiles_per_z : 0;
+    const int ntiles = p.partial ? max(0, min(p.K / 128 - kt0, p.k_tiles_per_z)) : p.K / 128;
 
     const uint8_t *a_src[4], *b_src[4];
 #pragma unroll
@@ -574,8 +580,8 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
         const int row   = (wave * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (row & 7);
         // rows past M (a partial last row tile) re-read row M - 1: valid memory, results never stored
-        a_src[i]        = (const uint8_t*)p.a + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk * 16;
-        b_src[i]        = (const uint8_t*)p.b + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 16; // likewise past N
+        a_src[i]        = (const uint8_t*)p.a + (size_t)min(m0 + row, p.M - 1) * p.lda + (size_t)kt0 * 128 + chunk * 16;
+        b_src[i]        = (const uint8_t*)p.b + (size_t)min(n0 + row, p.N - 1) * p.ldb + (size_t)kt0 * 128 + chunk * 16; // likewise past N
     }
     auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         uint8_t* sa = lds + buf * 2 * TILE;
@@ -629,6 +635,20 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
             compute(cur);
             __syncthreads();
         }
+    }
+    if(p.partial)
+    {
+        int32_t* slab = p.partial + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for(int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for(int mt = 0; mt < 4; ++mt)
+            {
+                const int n = n0 + wn * 64 + nt * 16 + fq * 4, m = m0 + wm * 64 + mt * 16 + fr;
+                if(m < p.M && n < p.N)
+                    *(i4_t*)(slab + (size_t)m * p.N + n) = acc[nt][mt];
+            }
+        return;
     }
     const float relu_floor = requant_relu_floor(p.kind);
 #pragma unroll
@@ -977,6 +997,33 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
     else
         ((uint16_t*)p.c)[(size_t)m * p.ldc + n] =
             cvt_out16(apply_epilogue(p.epi, acc, m, n), p.epi.c_dtype);
+}
+
+// Split-K of the int8 x int8 GEMM: sum the int32 slabs (exact in any order), then the requantisation of the kernels above.
+__global__ __launch_bounds__(256) void wq_reduce_requant_i8(const int32_t* __restrict__ partials, int k_batch, int M, int N,
+                                                            int8_t* c, int ldc, int kind, float requant,
+                                                            const int32_t* __restrict__ bias)
+{
+    const int n4           = N >> 2; // N % 4 == 0 is checked on the host
+    const long total       = (long)M * n4;
+    const float relu_floor = requant_relu_floor(kind);
+    for(long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    {
+        const int m = (int)(i / n4);
+        const int n = (int)(i % n4) * 4;
+        i4_t s      = *(const i4_t*)(partials + (size_t)m * N + n);
+        for(int z = 1; z < k_batch; ++z)
+        {
+            const i4_t v = *(const i4_t*)(partials + ((size_t)z * M + m) * N + n);
+            s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
+        }
+        i4_t bias4 = {0, 0, 0, 0};
+        if(kind >= 11)
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                bias4[j] = bias[n + j];
+        *(uint32_t*)(c + (size_t)m * ldc + n) = requant_pack4(s, bias4, relu_floor, requant);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

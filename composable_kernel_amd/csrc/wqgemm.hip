@@ -183,7 +183,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         if((p->epilogue == WQ_EPI_ADD_ACT_MUL_CLAMP || p->epilogue == WQ_EPI_ADD_RELU_MUL_CLAMP) && !p->d0)
             return fail(WQ_ERR_INVALID, "epilogue %d needs the int32 bias d0", p->epilogue);
         if(plan.partial)
-            return fail(WQ_ERR_UNSUPPORTED, "split-K is not implemented for the int8 requant GEMM");
+            return fail(WQ_ERR_UNSUPPORTED, "the int8 requant GEMM takes no k_batch or K slice from the caller (the planner splits short grids itself)");
         const bool tiled_i8 = p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
                               p->N % 4 == 0 && p->K % 128 == 0 && p->lda % 16 == 0 && p->ldb % 16 == 0 &&
                               p->ldc % 4 == 0 && (uintptr_t)p->a % 16 == 0 && (uintptr_t)p->b % 16 == 0 &&
@@ -196,6 +196,35 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         if(tiled_i8 && p->N % 256 == 0 && p->ldc % 16 == 0 && (uintptr_t)p->c % 16 == 0 && !(p->flags & WQ_FLAG_TILE_128) &&
            (((long)((p->M + 255) / 256) * (p->N / 256) >= 128 && wgs128 > 512) || (p->flags & WQ_FLAG_TILE_256)))
             plan.route = ROUTE_I8_MFMA256;
+        // A short grid on the 128-tile kernel: the planner's own split of K across blockIdx.z (int32 partials in the
+        // optional workspace, requantised by wq_reduce_requant_i8; one slice without a workspace).  Two workgroups
+        // share a CU, so the slice count is the one with the shortest chain on the busiest CU, as for the 16-bit
+        // 128-tile kernel below; slices in whole 128-k tiles, at least 512 k (1024 k once a CU holds two).
+        if(plan.route == ROUTE_I8_MFMA128 && wgs128 <= 128 && !(p->flags & WQ_FLAG_TILE_128))
+        {
+            int best_score = 0, kb = 1;
+            for(int c = 1; c <= 16 && wgs128 * c <= 512; ++c)
+            {
+                const int chain = (int)((wgs128 * c + 255) / 256);
+                if(p->K / c < (chain > 1 ? 1024 : 512))
+                    break;
+                const int score = 1000 * c / chain * (chain > 1 ? 11 : 10);
+                if(score > best_score)
+                    best_score = score, kb = c;
+            }
+            if(kb > 1)
+            {
+                const int per = wqgemm_splitk_kread(p->K, kb, 128);
+                kb            = (p->K + per - 1) / per;
+                if(kb > 1)
+                {
+                    plan.auto_split = true;
+                    plan.k_batch    = kb;
+                    plan.k_per_z    = per;
+                    plan.partial    = true;
+                }
+            }
+        }
         if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_I8_MFMA256)
             return fail(WQ_ERR_UNSUPPORTED, "WQ_FLAG_TILE_256 needs N to be a multiple of 256 and tile-aligned operands");
         if((p->flags & WQ_FLAG_TILE_128) && plan.route != ROUTE_I8_MFMA128)
@@ -699,6 +728,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.requant = p->requant_scale;
         gp.kind    = p->epilogue;
         gp.bias    = (const int32_t*)p->d0;
+        gp.partial = nullptr, gp.k_tiles_per_z = 0;
         static bool opted_in[64] = {}; // more than 64 KiB of dynamic LDS must be opted into once per device
         int dev                  = 0;
         WQ_HIP(hipGetDevice(&dev));
@@ -721,7 +751,10 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.requant = p->requant_scale;
         gp.kind    = p->epilogue;
         gp.bias    = (const int32_t*)p->d0;
-        hipLaunchKernelGGL(wq::wq_gemm_i8_mfma_128, dim3(gp.tiles_m * gp.tiles_n), dim3(256), 0, s, gp);
+        gp.partial = plan.partial ? (int32_t*)workspace : nullptr;
+        gp.k_tiles_per_z = plan.k_per_z / 128;
+        hipLaunchKernelGGL(wq::wq_gemm_i8_mfma_128, dim3(gp.tiles_m * gp.tiles_n, 1, plan.partial ? plan.k_batch : 1), dim3(256), 0,
+                           s, gp);
     }
     else
     {
@@ -768,6 +801,13 @@ int launch_reduce(const wqgemm_problem* p, const float* partials, int k_batch, h
     int blocks      = (int)((work + 255) / 256);
     if(blocks > 4096)
         blocks = 4096;
+    if(p->a_dtype == WQ_I8)
+    {
+        hipLaunchKernelGGL(wq::wq_reduce_requant_i8, dim3(blocks), dim3(256), 0, s, (const int32_t*)partials, k_batch, p->M, p->N,
+                           (int8_t*)p->c, p->ldc, p->epilogue, p->requant_scale, (const int32_t*)p->d0);
+        WQ_HIP(hipGetLastError());
+        return WQ_OK;
+    }
     hipLaunchKernelGGL(wq::wq_reduce_finalize, dim3(blocks), dim3(256), 0, s, partials, k_batch,
                        p->M, p->N, p->N, p->c, p->ldc, epilogue_of(p));
     WQ_HIP(hipGetLastError());

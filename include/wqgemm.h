@@ -113,7 +113,7 @@ typedef struct wqgemm_problem
     const void* d0;
     const void* d1;
     /* Split-K.  k_batch > 1 splits K inside one GPU: slice z reads [z*KRead, min(K,(z+1)*KRead)),
-     * KRead = ceil(K/(k_batch*64))*64 (gridwise_gemm_xdl_cshuffle_v3.hpp:192-197,583-590), fp32
+     * KRead = ceil(K/(k_batch*64))*64, 128 in place of 64 for fp8 activations (gridwise_gemm_xdl_cshuffle_v3.hpp:192-197,583-590), fp32
      * partials go to the caller's workspace and a reduce kernel applies the epilogue
      * (device_gemm_xdl_cshuffle_v3r1.hpp:209-270).
      * k_begin/k_end (k_end > k_begin) restrict the whole call to one K slice and make it store
@@ -166,8 +166,9 @@ int wqgemm_is_supported(const wqgemm_problem* p);
 /* Bytes of device workspace wqgemm_launch can use:
  *  - k_batch*M*N*4 when the caller sets k_batch > 1 (required: the launch fails with WQ_ERR_WORKSPACE
  *    without it), plus K*N for tile-aligned row-major (K x N) 8-bit weights (their K-contiguous copy follows the slabs);
- *  - kb*M*N*4 when the planner itself splits K (small-M problems, and short grids of the 128-tile kernel; kb chosen
- *    so the grid fills the chip;
+ *  - kb*M*N*4 when the planner itself splits K (small-M problems; grids shorter than the chip on the 128- and 256-tile
+ *    kernels, the fp8 kernel and the int8 x int8 128-tile kernel, whose partials are int32; kb chosen so the grid
+ *    fills the chip;
  *    optional: without it the launch runs the whole K range as one slice);
  *  - (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
  *    fp16 image of A for the fp16 matrix-core kernel);

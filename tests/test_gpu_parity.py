@@ -586,7 +586,7 @@ def test_bf16_int8_mfma(port):
     np.testing.assert_array_equal(got, exp)
 
 
-def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None, bias=None, relu=False):
+def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None, bias=None, relu=False, use_workspace=True):
     a_t, b_t = dev(a), dev(b)
     ldc = ldc or N
     e_t = torch.full((M + 16, ldc), 77, dtype=torch.int8, device="cuda")  # 16 guard rows
@@ -598,7 +598,9 @@ def _run_i8(a, b, M, N, K, requant, flags=0, lda=None, ldb=None, ldc=None, bias=
                              d0=bias_t.data_ptr() if bias_t is not None else None,
                              flags=flags, lda=lda, ldb=ldb, ldc=ldc)
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
-    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+    nbytes = capi.workspace_bytes(p)   # the planner's own split-K of a short grid (optional)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes and use_workspace else None
+    capi.launch(p, ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     e = e_t.cpu().numpy()
     assert (e[M:] == 77).all(), "rows past M were written"
@@ -1635,6 +1637,31 @@ def test_planner_split_k_on_the_256_tile_kernel(port, b_dtype):
     for use_ws in (True, False):
         got = run_fpaintb(a, b, s, M, N, K, b_dtype=b_dtype, use_workspace=use_ws)
         check_err(bits_to_f32(got[rows], capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
+def test_int8_requant_planner_split_k(port):
+    """Short grids of the int8 x int8 GEMM (decode- and prefill-chunk-sized M): the planner splits K across blockIdx.z
+    into int32 partials and requantises in the reduction.  Integer arithmetic: bit-equal to the CPU checker, to the
+    general kernel and to the single-slice launch (no workspace), bias and Relu included; ragged M and N."""
+    rng = np.random.default_rng(88)
+    for (M, N, K, bias_on, relu) in ((16, 1024, 4096, False, False), (100, 516, 2048, True, True), (300, 1024, 8192, True, False),
+                                     (1, 256, 1024, False, True), (64, 4096, 4096, True, True)):
+        a = rng.integers(-128, 128, (M, K)).astype(np.int8)
+        b = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        bias = rng.integers(-50000, 50001, N).astype(np.int32) if bias_on else None
+        rq = 0.002
+        e, name = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu)
+        p = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, M, N, K, a_dtype=capi.I8, b_dtype=capi.I8, c_dtype=capi.I8,
+                                 epilogue=capi.EPI_ACT_MUL_CLAMP, requant=rq)
+        assert name == "wq_gemm_i8_mfma_128" and capi.workspace_bytes(p) > 0 and "KBatch1>" not in capi.type_string(p), capi.type_string(p)
+        one, _ = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu, use_workspace=False)
+        g, gname = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu, flags=capi.FLAG_GENERIC)
+        assert gname == GENERIC
+        np.testing.assert_array_equal(e, g)
+        np.testing.assert_array_equal(one, g)
+        if bias is None and not relu:
+            exp = port.gemm_i8_requant(a, b, M, N, K, K, K, N, rq).reshape(M, N)
+            np.testing.assert_array_equal(e, exp)
 
 
 def test_torch_linear_preshuffled_weights(tmp_path):

@@ -158,7 +158,7 @@ def one_case(rng) -> dict:
     return desc
 
 
-def _run_i8(a, b, M, N, K, requant, flags, lda, ldb, ldc, bias, relu):
+def _run_i8(a, b, M, N, K, requant, flags, lda, ldb, ldc, bias, relu, use_workspace=True):
     a_t, b_t = dev(a), dev(b)
     e_t = torch.full((M + 16, ldc), 77, dtype=torch.int8, device="cuda")   # 16 guard rows
     bias_t = dev(np.ascontiguousarray(bias, np.int32)) if bias is not None else None
@@ -169,16 +169,18 @@ def _run_i8(a, b, M, N, K, requant, flags, lda, ldb, ldc, bias, relu):
                              flags=flags, lda=lda, ldb=ldb, ldc=ldc)
     if not capi.is_supported(p):
         return None, None
-    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+    nbytes = capi.workspace_bytes(p)   # the planner's own split-K of a short grid: optional
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes and use_workspace else None
+    capi.launch(p, ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    return e_t.cpu().numpy(), capi.kernel_name(p)
+    return e_t.cpu().numpy(), capi.kernel_name(p) + ("+splitk" if ws is not None else "")
 
 
 def one_case_i8(rng) -> dict:
     """int8 x int8 -> int8 behind the requantisation epilogues: integer accumulation, so random data is exact."""
     M = int(rng.choice([1, 5, 16, 64, 100, 128, 200, 256, 300, 513, 1024, 2048]))
     N = int(rng.choice([16, 100, 128, 256, 384, 512, 1024, 2048, 4096]))
-    K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 4096]))
+    K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 4096, 5120, 8192]))
     lda, ldb, ldc = K + int(rng.choice([0, 0, 16, 128])), K + int(rng.choice([0, 0, 16, 128])), N + int(rng.choice([0, 0, 16]))
     a = rng.integers(-128, 128, (M, lda)).astype(np.int8)
     b = rng.integers(-128, 128, (N, ldb)).astype(np.int8)
@@ -186,9 +188,10 @@ def one_case_i8(rng) -> dict:
     relu = bool(rng.integers(0, 2))
     rq = float(rng.choice([1e-4, 1e-3, 0.03]))
     flags = (0, capi.FLAG_TILE_128, capi.FLAG_TILE_256)[int(rng.integers(0, 3))]
-    got, kernel = _run_i8(a, b, M, N, K, rq, flags, lda, ldb, ldc, bias, relu)
+    use_ws = bool(rng.integers(0, 4))
+    got, kernel = _run_i8(a, b, M, N, K, rq, flags, lda, ldb, ldc, bias, relu, use_ws)
     if got is None:
-        got, kernel = _run_i8(a, b, M, N, K, rq, 0, lda, ldb, ldc, bias, relu)
+        got, kernel = _run_i8(a, b, M, N, K, rq, 0, lda, ldb, ldc, bias, relu, use_ws)
     ref, _ = _run_i8(a, b, M, N, K, rq, capi.FLAG_GENERIC, lda, ldb, ldc, bias, relu)
     desc = dict(fmt="i8xi8", M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, bias=bias is not None, relu=relu, requant=rq, k_batch=1,
                 kernel=kernel)
