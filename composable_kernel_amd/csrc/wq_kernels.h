@@ -904,10 +904,11 @@ __global__ __launch_bounds__(256) void wq_transpose_b8(const uint8_t* b, int ldb
     }
 }
 
-// fp8 FNUZ activations -> fp16 (exact: every FNUZ value, NaN included, is an fp16 value), 8 per thread, into a
-// dense [M][K] image; also fills `ones` (N fp16 values 1.0, the unit weight scale of the fp16 GEMM that follows).
+// fp8 activations (FNUZ, or OCP E4M3FN when fn != 0) -> fp16 (exact: every value of either format, NaN included, is
+// an fp16 value), 8 per thread, into a dense [M][K] image; also fills `ones` (N fp16 values 1.0, the unit weight scale
+// of the fp16 GEMM that follows).
 __global__ __launch_bounds__(256) void wq_f8_fnuz_to_f16(const uint8_t* a, int lda, int M, int K, uint16_t* out,
-                                                         uint16_t* ones, int N)
+                                                         uint16_t* ones, int N, int fn)
 {
     const long groups = (long)M * (K / 8);
     for(long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long)gridDim.x * blockDim.x)
@@ -919,8 +920,9 @@ __global__ __launch_bounds__(256) void wq_f8_fnuz_to_f16(const uint8_t* a, int l
         for(int i = 0; i < 4; ++i)
         {
             const uint32_t w  = raw[i >> 1] >> (16 * (i & 1));
-            const _Float16 lo = (_Float16)f8_fnuz_to_f32((uint8_t)(w & 0xFF));
-            const _Float16 hi = (_Float16)f8_fnuz_to_f32((uint8_t)((w >> 8) & 0xFF));
+            const uint8_t b0 = (uint8_t)(w & 0xFF), b1 = (uint8_t)((w >> 8) & 0xFF);
+            const _Float16 lo = (_Float16)(fn ? f8_e4m3fn_to_f32(b0) : f8_fnuz_to_f32(b0));
+            const _Float16 hi = (_Float16)(fn ? f8_e4m3fn_to_f32(b1) : f8_fnuz_to_f32(b1));
             o[i] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
         }
         *(u4_t*)(out + (size_t)m * K + k8 * 8) = o;

@@ -125,7 +125,7 @@ int check_fp_epilogue(const wqgemm_problem* p)
 }
 
 // Validate and choose a kernel.  Returns WQ_OK and fills plan, or an error status with message.
-int make_plan(const wqgemm_problem* p, Plan& plan)
+int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
 {
     if(!p)
         return fail(WQ_ERR_INVALID, "null problem");
@@ -306,6 +306,24 @@ int make_plan(const wqgemm_problem* p, Plan& plan)
         // occupy the chip and K is short enough that splitting it across the grid would not pay for a second kernel
         // (every workgroup reads all M rows of the activations: N / 16 * M * K * 2 bytes from L2 in total, four times
         // what the grid-split kernel reads; measured break-even near 96 MB)
+        // fp8 activations at M <= 16 (decode): their fp16 image (exact, M * K * 2 bytes in the workspace) lets the same
+        // streaming kernel read the weights once at HBM speed; the fp8 tile kernel would spend a 256-row tile on them.
+        // Only with a workspace, packed int4 weights, fp16 C; the tile kernel (or, for FNUZ bytes that may hold the
+        // special encodings, the image through the 128-tile kernel) otherwise.
+        const bool f8_image = !is16(p->a_dtype) && have_workspace && is_i4(p->b_dtype) && p->c_dtype == WQ_F16 && p->K % 8 == 0 &&
+                              !(p->flags & WQ_FLAG_PINGPONG);
+        const bool eligible_f8 = f8_image && p->M <= 16 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
+                                 p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 && klen_all % ks == 0 &&
+                                 p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 8 == 0 && p->lda % 8 == 0 &&
+                                 (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0;
+        if(eligible_f8 && !slice && plan.k_batch == 1 && klen_all / ks >= 4 && p->N / 16 >= 128 &&
+           (klen_all <= 8192 || (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024) && (long)(p->N / 16) * p->M * klen_all * 2 <= 96L * 1000 * 1000)
+        {
+            plan.via_f16 = true;
+            plan.ak      = wq::A_F16;
+            plan.route   = ROUTE_SKINNY_WS;
+            return WQ_OK;
+        }
         if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all / ks >= 4 && p->N % 16 == 0 &&
            p->N / 16 >= 128 && (klen_all <= 8192 || (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024) && // (chunked variant: short K only)
            (long)(p->N / 16) * p->M * klen_all * 2 <= 96L * 1000 * 1000)
@@ -556,6 +574,24 @@ void launch_mfma128(const wq::GemmParams& gp, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((wq::wq_gemm_mfma_128<AK, BKIND>), grid, dim3(256), 0, s, gp);
 }
 
+// fp8 activations through the 16-bit kernels: workspace = [M][K] fp16 image of A, then N fp16 ones (the unit weight scale)
+void f16_image_of_a(const wqgemm_problem* p, void* workspace, hipStream_t s, wq::GemmParams& gp)
+{
+    uint16_t* a16     = (uint16_t*)workspace;
+    uint16_t* ones    = a16 + (size_t)p->M * p->K;
+    const long groups = (long)p->M * (p->K / 8);
+    int blocks        = (int)((groups + 255) / 256);
+    if(blocks > 8192)
+        blocks = 8192;
+    if(blocks < 1)
+        blocks = 1;
+    hipLaunchKernelGGL(wq::wq_f8_fnuz_to_f16, dim3(blocks), dim3(256), 0, s, (const uint8_t*)p->a, p->lda, p->M, p->K, a16, ones,
+                       p->N, p->a_dtype == WQ_F8_E4M3FN ? 1 : 0);
+    gp.a     = a16;
+    gp.scale = ones;
+    gp.lda   = p->K;
+}
+
 int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipStream_t s)
 {
     void* out  = plan.partial && !plan.to_c ? workspace : p->c;
@@ -577,20 +613,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
             gp.ldb_bytes = p->K;
         }
         if(plan.via_f16)
-        {
-            // workspace = [M][K] fp16 image of A, then N fp16 ones
-            uint16_t* a16  = (uint16_t*)workspace;
-            uint16_t* ones = a16 + (size_t)p->M * p->K;
-            const long groups = (long)p->M * (p->K / 8);
-            int blocks        = (int)((groups + 255) / 256);
-            if(blocks > 8192)
-                blocks = 8192;
-            hipLaunchKernelGGL(wq::wq_f8_fnuz_to_f16, dim3(blocks), dim3(256), 0, s, (const uint8_t*)p->a, p->lda, p->M,
-                               p->K, a16, ones, p->N);
-            gp.a     = a16;
-            gp.scale = ones;
-            gp.lda   = p->K;
-        }
+            f16_image_of_a(p, workspace, s, gp);
         gp.c         = out;
         gp.M         = p->M;
         gp.N         = p->N;
@@ -702,6 +725,8 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.epi     = epilogue_of(p);
         gp.b_preshuf = is_preshuf(p->b_dtype) ? 1 : 0;
         set_scale_groups(gp, p);
+        if(plan.via_f16)
+            f16_image_of_a(p, workspace, s, gp);
         const int ks = is_i4(p->b_dtype) ? 128 : 64, klen = plan.k_end - plan.k_begin;
         // loads in flight = super-steps per unit of K dealt to a wave: as many as leave every wave at least one unit
         const int steps   = klen / ks;
@@ -914,7 +939,7 @@ size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
 int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
 {
     Plan plan;
-    const int rc = make_plan(p, plan);
+    const int rc = make_plan(p, plan, workspace != nullptr);
     if(rc != WQ_OK)
         return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -1664,6 +1664,41 @@ def test_int8_requant_planner_split_k(port):
             np.testing.assert_array_equal(e, exp)
 
 
+@pytest.mark.parametrize("fn", [True, False])
+def test_f8_int4_decode_through_the_streaming_kernel(port, fn):
+    """fp8 activations at M <= 16: the planner converts them to their (exact) fp16 image in the workspace and runs the
+    small-M streaming kernel.  Every byte code of the format, the special ones included, against the general kernel
+    bit for bit on exact data (all 256 codes appear; NaN positions compared as NaN), realistic data against the CPU
+    checker; plain and pre-shuffled weights; without a workspace the fp8 tile kernel gives the same bits on exact data."""
+    rng = np.random.default_rng(165)
+    a_dtype = capi.F8_E4M3FN if fn else capi.F8_FNUZ
+    lut = {0: 0x00, 1: 0x38, 2: 0x40, -1: 0xB8, -2: 0xC0} if fn else {0: 0x00, 1: 0x40, 2: 0x48, -1: 0xC0, -2: 0xC8}
+    for (M, N, K, pre) in ((1, 2048, 1024, False), (8, 4096, 4096, True), (16, 2048, 2048, False)):
+        q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+        packed = pack_on_device(q, K, N)
+        b = preshuffle_on_device(packed, K, N) if pre else packed
+        b_dtype = capi.I4_PRESHUFFLED if pre else capi.I4_PACKED
+        d0 = (2.0 ** rng.integers(-6, -2, N)).astype(np.float32)
+        d1 = (2.0 ** rng.integers(-3, 1, M)).astype(np.float32)
+        kw = dict(a_dtype=a_dtype, epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU, d0=d0, d1=d1)
+        a = np.vectorize(lut.get)(rng.integers(-2, 3, (M, K))).astype(np.uint8)
+        name = "wq_f8_fnuz_to_f16+wq_gemm_skinny_ws" + ("c" if M * (K * 2 + 16) > 40 * 1024 else "")
+        got = run_fpaintb(a, b, None, M, N, K, b_dtype=b_dtype, expect_kernel=name, **kw)
+        ref = run_fpaintb(a, packed, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC, **kw)
+        np.testing.assert_array_equal(got, ref)
+        tile = run_fpaintb(a, b, None, M, N, K, b_dtype=b_dtype, use_workspace=False,
+                           flags=0 if fn else capi.FLAG_F8_NO_SPECIALS, **kw)
+        np.testing.assert_array_equal(tile, ref)
+        # every byte code, plain MultiplyMultiply: equal to the general kernel wherever that is a number, NaN where it is NaN
+        a_all = rng.integers(0, 256, (M, K)).astype(np.uint8)
+        kw2 = dict(a_dtype=a_dtype, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=d0, d1=d1)
+        got = bits_to_f32(run_fpaintb(a_all, b, None, M, N, K, b_dtype=b_dtype, expect_kernel=name, **kw2), capi.F16)
+        ref = bits_to_f32(run_fpaintb(a_all, packed, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel=GENERIC, **kw2), capi.F16)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        check_err(got[ok], ref[ok], 1e-3, 1e-3)
+
+
 def test_torch_linear_preshuffled_weights(tmp_path):
     """Pre-shuffled int4 weights through the container and the torch operator: the same bits as the packed layout of
     the same weights (same kernel arithmetic), for a prefill-sized and a decode-sized batch and for an N that only the

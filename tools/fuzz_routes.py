@@ -208,7 +208,7 @@ def one_case_f8(rng) -> dict:
     """fp8 x int4 + MultiplyMultiply[+FastGelu] on the fp8 matrix core, both byte formats, plain and pre-shuffled
     weights: small integers as activations and power-of-two factors keep every sum exact."""
     M = int(rng.choice([1, 7, 16, 64, 65, 100, 128, 256, 300, 512, 700, 1024, 2048]))
-    N = int(rng.choice([256, 512, 1024, 2048, 4096]))
+    N = int(rng.choice([256, 512, 1024, 2048, 4096, 8192]))
     K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 4096]))
     fn = bool(rng.integers(0, 2))
     pre = bool(rng.integers(0, 2))
@@ -233,10 +233,15 @@ def one_case_f8(rng) -> dict:
     if not pre and rng.integers(0, 4) == 0:
         flags |= capi.FLAG_PINGPONG
     ref = run_fpaintb(a, plain, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel="wq_gemm_generic", **kw)
-    got = run_fpaintb(a, b, None, M, N, K, b_dtype=capi.I4_PRESHUFFLED if pre else capi.I4_PACKED, flags=flags, k_batch=kb,
-                      expect_kernel="wq_gemm_f8_mfma_256", use_workspace=bool(kb > 1 or rng.integers(0, 3)), **kw)
+    b_dtype = capi.I4_PRESHUFFLED if pre else capi.I4_PACKED
+    probe = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, M, N, K, a_dtype=kw["a_dtype"], c_dtype=capi.F16, b_dtype=b_dtype,
+                                 lda=lda, ldc=kw.get("ldc"), epilogue=kw["epilogue"], d0=1 << 20, d1=1 << 20, k_batch=kb, flags=flags)
+    kernel = capi.kernel_name(probe)   # the fp8 tile kernel, or (M <= 16) the fp16 image + streaming kernel
+    assert kernel in ("wq_gemm_f8_mfma_256", "wq_f8_fnuz_to_f16+wq_gemm_skinny_ws", "wq_f8_fnuz_to_f16+wq_gemm_skinny_wsc"), kernel
+    got = run_fpaintb(a, b, None, M, N, K, b_dtype=b_dtype, flags=flags, k_batch=kb,
+                      use_workspace=bool(kb > 1 or rng.integers(0, 3)), **kw)
     desc = dict(fmt="f8xi4" + ("pre" if pre else ""), e4m3fn=fn, M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), gelu=gelu, k_batch=kb,
-                flags=flags, kernel="wq_gemm_f8_mfma_256")
+                flags=flags, kernel=kernel)
     # (an output still holding the poison pattern everywhere would compare equal: that is a failure too)
     desc["equal"] = bool(np.array_equal(got[:, :N], ref[:, :N]) and (got[:, :N] != 0x7BFF).any())
     desc["padding_untouched"] = bool((got[:, N:] == 0x7BFF).all())
