@@ -527,4 +527,27 @@ __device__ __forceinline__ uint16_t cvt_out16(float v, int c_dtype)
     return __builtin_bit_cast(uint16_t, (_Float16)v);
 }
 
+__device__ __forceinline__ float f8_fnuz_to_f32(uint8_t x)
+{
+    // E4M3 FNUZ: bias 8, 0x80 = NaN, subnormals m * 2^-10 (f8_utils.hpp:186-267)
+    if(x == 0x80)
+        return __builtin_nanf("");
+    const int e   = (x >> 3) & 15;
+    const int m   = x & 7;
+    const float v = e == 0 ? (float)m * 0.0009765625f : __builtin_ldexpf((float)(8 + m), e - 11);
+    return (x & 0x80) ? -v : v;
+}
+
+__device__ __forceinline__ float f8_e4m3fn_to_f32(uint8_t x)
+{
+    // OCP E4M3 ("e4m3fn"): bias 7, S.1111.111 = NaN, no infinities, subnormals m * 2^-9
+    if((x & 0x7F) == 0x7F)
+        return __builtin_nanf("");
+    const int e   = (x >> 3) & 15;
+    const int m   = x & 7;
+    const float v = e == 0 ? (float)m * 0.001953125f : __builtin_ldexpf((float)(8 + m), e - 10);
+    return (x & 0x80) ? -v : v;
+}
+
+
 } // namespace wq

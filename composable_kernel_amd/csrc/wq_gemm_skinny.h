@@ -304,12 +304,30 @@ __global__ __launch_bounds__(256) void wq_gemm_skinny_ws(const GemmParams p)
     {
         const int chunks_per_row = klen / 8;
         const int total          = p.M * chunks_per_row;
-        for(int i = threadIdx.x; i < total; i += 256)
-        {
-            const int row = i / chunks_per_row, ch = i - row * chunks_per_row;
-            *(u4_t*)(lds + row * pitch + ch * 16) =
-                *(const u4_t*)((const uint8_t*)p.a + ((size_t)row * p.lda + p.k_begin) * 2 + ch * 16);
-        }
+        if(p.a_f8) // fp8 bytes: eight of them become the same 16 bytes of fp16 (every fp8 value is an fp16 value)
+            for(int i = threadIdx.x; i < total; i += 256)
+            {
+                const int row  = i / chunks_per_row, ch = i - row * chunks_per_row;
+                const u2_t raw = *(const u2_t*)((const uint8_t*)p.a + (size_t)row * p.lda + p.k_begin + ch * 8);
+                u4_t o;
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+                {
+                    const uint32_t w = raw[j >> 1] >> (16 * (j & 1));
+                    const uint8_t b0 = (uint8_t)(w & 0xFF), b1 = (uint8_t)((w >> 8) & 0xFF);
+                    const _Float16 lo = (_Float16)(p.a_f8 == 2 ? f8_e4m3fn_to_f32(b0) : f8_fnuz_to_f32(b0));
+                    const _Float16 hi = (_Float16)(p.a_f8 == 2 ? f8_e4m3fn_to_f32(b1) : f8_fnuz_to_f32(b1));
+                    o[j] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+                }
+                *(u4_t*)(lds + row * pitch + ch * 16) = o;
+            }
+        else
+            for(int i = threadIdx.x; i < total; i += 256)
+            {
+                const int row = i / chunks_per_row, ch = i - row * chunks_per_row;
+                *(u4_t*)(lds + row * pitch + ch * 16) =
+                    *(const u4_t*)((const uint8_t*)p.a + ((size_t)row * p.lda + p.k_begin) * 2 + ch * 16);
+            }
     }
     ScaleReg<AK> sc;
     sc.set(GROUPED ? unit_scale_bits<AK>() : (p.scale ? ((const uint16_t*)p.scale)[n0 + fr] : unit_scale_bits<AK>()));

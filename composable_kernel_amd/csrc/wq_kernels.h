@@ -39,6 +39,8 @@ struct GemmParams
     int scale_group_k; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
     int ld_scale;
     int scale_group_shift; // log2(scale_group_k) when that is a power of two (small-M kernels), else -1
+    int a_f8;          // small-M whole-image kernel only: a holds fp8 bytes (1: E4M3 FNUZ, 2: OCP E4M3FN; lda in bytes), widened
+                       // to fp16 (exact) on their way into LDS; 0: a holds the 16-bit activations
     int b_preshuf;     // weights in the pre-shuffled order (1 KiB blocks of 64 k x 32 columns of packed int4 or x 16
                        // columns of int8; column-block pitch = 32 * ldb_bytes or 16 * ldb_bytes): 256-tile kernels only
 };
@@ -847,28 +849,6 @@ struct GenericParams
     EpilogueArgs epi;
     int scale_group_k, ld_scale; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
 };
-
-__device__ __forceinline__ float f8_fnuz_to_f32(uint8_t x)
-{
-    // E4M3 FNUZ: bias 8, 0x80 = NaN, subnormals m * 2^-10 (f8_utils.hpp:186-267)
-    if(x == 0x80)
-        return __builtin_nanf("");
-    const int e   = (x >> 3) & 15;
-    const int m   = x & 7;
-    const float v = e == 0 ? (float)m * 0.0009765625f : __builtin_ldexpf((float)(8 + m), e - 11);
-    return (x & 0x80) ? -v : v;
-}
-
-__device__ __forceinline__ float f8_e4m3fn_to_f32(uint8_t x)
-{
-    // OCP E4M3 ("e4m3fn"): bias 7, S.1111.111 = NaN, no infinities, subnormals m * 2^-9
-    if((x & 0x7F) == 0x7F)
-        return __builtin_nanf("");
-    const int e   = (x >> 3) & 15;
-    const int m   = x & 7;
-    const float v = e == 0 ? (float)m * 0.001953125f : __builtin_ldexpf((float)(8 + m), e - 10);
-    return (x & 0x80) ? -v : v;
-}
 
 // 8-bit weights (K, N) row-major (N contiguous, ld = ldb) -> (N, K) with K contiguous, the operand order of the
 // matrix-core kernels.  64 x 64 byte tiles through LDS; K and N are multiples of 64.

@@ -80,6 +80,7 @@ struct Plan
     bool partial  = false; // main kernel writes fp32 partial slabs
     bool to_c     = false; // ... directly into p->c (multi-GPU slice) instead of the workspace
     bool auto_split = false; // split-K chosen by the planner (small-M kernel, short grids of the 128-tile kernel): needs, and is dropped without, a workspace
+    bool f8_fused   = false; // fp8 activations widened inside the small-M whole-image kernel (no image in the workspace)
     bool split_256  = false; // the planner's split-K is what put this problem on the 256-tile kernel
     bool via_colb = false; // row-major 8-bit B: transpose into the workspace, then the K-contiguous matrix-core kernels
     bool via_f16  = false; // fp8 FNUZ activations: convert to fp16 in the workspace, then the fp16 MFMA kernel
@@ -310,8 +311,13 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         // streaming kernel read the weights once at HBM speed; the fp8 tile kernel would spend a 256-row tile on them.
         // Only with a workspace, packed int4 weights, fp16 C; the tile kernel (or, for FNUZ bytes that may hold the
         // special encodings, the image through the 128-tile kernel) otherwise.
-        const bool f8_image = !is16(p->a_dtype) && have_workspace && is_i4(p->b_dtype) && p->c_dtype == WQ_F16 && p->K % 8 == 0 &&
-                              !(p->flags & WQ_FLAG_PINGPONG);
+        // (when the whole image fits the kernel's LDS budget the kernel widens the bytes itself: no workspace, one launch)
+        // (every workgroup widens the whole image for itself: beyond some 8M conversions per row of activations -- 28672
+        // columns x 8192 k: 32.2 against 29.3 us -- one pass into the workspace is cheaper when there is one)
+        const bool f8_fused = (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024 &&
+                              (!have_workspace || (long)(p->N / 16) * klen_all <= 8L * 1000 * 1000);
+        const bool f8_image = !is16(p->a_dtype) && (have_workspace || f8_fused) && is_i4(p->b_dtype) && p->c_dtype == WQ_F16 &&
+                              p->K % 8 == 0 && !(p->flags & WQ_FLAG_PINGPONG);
         const bool eligible_f8 = f8_image && p->M <= 16 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                                  p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 && klen_all % ks == 0 &&
                                  p->ldb % b_row_align == 0 && p->ldc % 4 == 0 && (uintptr_t)p->a % 8 == 0 && p->lda % 8 == 0 &&
@@ -319,9 +325,10 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         if(eligible_f8 && !slice && plan.k_batch == 1 && klen_all / ks >= 4 && p->N / 16 >= 128 &&
            (klen_all <= 8192 || (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024) && (long)(p->N / 16) * p->M * klen_all * 2 <= 96L * 1000 * 1000)
         {
-            plan.via_f16 = true;
-            plan.ak      = wq::A_F16;
-            plan.route   = ROUTE_SKINNY_WS;
+            plan.via_f16  = !f8_fused;
+            plan.f8_fused = f8_fused;
+            plan.ak       = wq::A_F16;
+            plan.route    = ROUTE_SKINNY_WS;
             return WQ_OK;
         }
         if(eligible && p->M <= 16 && !slice && plan.k_batch == 1 && klen_all / ks >= 4 && p->N % 16 == 0 &&
@@ -600,6 +607,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
     {
         const int tile = plan.route == ROUTE_MFMA128 ? 128 : 256;
         wq::GemmParams gp;
+        gp.a_f8      = 0;
         gp.a         = p->a;
         gp.b         = p->b;
         gp.scale     = p->scale;
@@ -727,6 +735,8 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         set_scale_groups(gp, p);
         if(plan.via_f16)
             f16_image_of_a(p, workspace, s, gp);
+        if(plan.f8_fused)
+            gp.a_f8 = p->a_dtype == WQ_F8_E4M3FN ? 2 : 1;
         const int ks = is_i4(p->b_dtype) ? 128 : 64, klen = plan.k_end - plan.k_begin;
         // loads in flight = super-steps per unit of K dealt to a wave: as many as leave every wave at least one unit
         const int steps   = klen / ks;

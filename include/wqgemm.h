@@ -171,8 +171,9 @@ int wqgemm_is_supported(const wqgemm_problem* p);
  *    fills the chip;
  *    optional: without it the launch runs the whole K range as one slice);
  *  - (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
- *    fp16 image of A for the fp16 matrix-core kernel), and for fp8 activations of either format at M <= 16 (optional:
- *    the same image feeds the small-M streaming kernel; without it the fp8 matrix-core kernel runs);
+ *    fp16 image of A for the fp16 matrix-core kernel), and for fp8 activations of either format at M <= 16 when the
+ *    image is too large for the small-M streaming kernel to build in LDS by itself (optional: without it the fp8
+ *    matrix-core kernel runs);
  *  - K*N for tile-aligned row-major (K x N) 8-bit weights (optional: holds the K-contiguous transpose the
  *    matrix-core kernels read);
  *  - else 0.

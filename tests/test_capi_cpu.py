@@ -378,10 +378,12 @@ def test_fp8_activations_short_grids_split_k_and_small_m():
     """fp8 activations: every M runs on the fp8 matrix-core kernel (no general-kernel fallback for decode-sized
     batches), and a grid shorter than the chip gets the planner's own K split (optional workspace)."""
     f8 = dict(a_dtype=capi.F8_E4M3FN, c_dtype=capi.F16, scale=None, epilogue=capi.EPI_MULTIPLY_MULTIPLY, d0=0x10000, d1=0x10000)
-    for M in (1, 16):                                     # decode: fp16 image of A, then the streaming kernel (one pass over B)
-        p = _problem(M=M, **f8)
-        assert capi.kernel_name(p).startswith("wq_f8_fnuz_to_f16+wq_gemm_skinny_ws")   # (whole image in LDS, or chunked)
-        assert capi.workspace_bytes(p) == (M * 4096 + 4096) * 2
+    # decode: the streaming kernel (one pass over B); it widens the bytes itself while the fp16 image fits its LDS budget
+    # (no workspace then), else a first kernel writes the image to the workspace
+    p = _problem(M=1, **f8)
+    assert capi.kernel_name(p) == "wq_gemm_skinny_ws" and capi.workspace_bytes(p) == 0
+    p = _problem(M=16, **f8)
+    assert capi.kernel_name(p) == "wq_f8_fnuz_to_f16+wq_gemm_skinny_wsc" and capi.workspace_bytes(p) == (16 * 4096 + 4096) * 2
     assert capi.kernel_name(_problem(M=16, flags=capi.FLAG_PINGPONG, **f8)) == "wq_gemm_f8_mfma_256"   # a kernel asked for by name
     for M in (17, 64, 65, 512):
         p = _problem(M=M, **f8)

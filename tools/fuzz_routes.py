@@ -237,7 +237,7 @@ def one_case_f8(rng) -> dict:
     probe = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, M, N, K, a_dtype=kw["a_dtype"], c_dtype=capi.F16, b_dtype=b_dtype,
                                  lda=lda, ldc=kw.get("ldc"), epilogue=kw["epilogue"], d0=1 << 20, d1=1 << 20, k_batch=kb, flags=flags)
     kernel = capi.kernel_name(probe)   # the fp8 tile kernel, or (M <= 16) the fp16 image + streaming kernel
-    assert kernel in ("wq_gemm_f8_mfma_256", "wq_f8_fnuz_to_f16+wq_gemm_skinny_ws", "wq_f8_fnuz_to_f16+wq_gemm_skinny_wsc"), kernel
+    assert kernel in ("wq_gemm_f8_mfma_256", "wq_gemm_skinny_ws", "wq_f8_fnuz_to_f16+wq_gemm_skinny_wsc"), kernel
     got = run_fpaintb(a, b, None, M, N, K, b_dtype=b_dtype, flags=flags, k_batch=kb,
                       use_workspace=bool(kb > 1 or rng.integers(0, 3)), **kw)
     desc = dict(fmt="f8xi4" + ("pre" if pre else ""), e4m3fn=fn, M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), gelu=gelu, k_batch=kb,
