@@ -1470,6 +1470,33 @@ def test_torch_linear_group_wise_scales(tmp_path):
         lin(x.cuda())
 
 
+@pytest.mark.parametrize("layout", ["packed", "preshuffled"])
+def test_torch_linear_group_wise_scales_bf16(tmp_path, layout):
+    """The same through bf16 activations and 8-bit weights (the Multiply-on-B form with a scale row per group), for a
+    prefill-sized, a chunk-sized (planner split-K) and a decode-sized batch, plain and pre-shuffled weight order:
+    against a float64 matmul with the dequantised weights within the bf16 bar (one truncation of a sum of 1024 terms)."""
+    from composable_kernel_amd import weights
+    from composable_kernel_amd.torch_ops import WqLinear
+    rng = np.random.default_rng(129)
+    N, K, group_k = 512, 1024, 128
+    w = (rng.normal(0, 0.05, (N, K)) * np.linspace(0.2, 3.0, K)[None, :]).astype(np.float32)
+    q, s = weights.quantize_per_group(w, group_k, 8, "bf16")
+    pw = weights.pack(q, s, 8, "bf16", group_k)
+    if layout == "preshuffled":
+        pw = weights.preshuffle(pw)
+    path = str(tmp_path / "grouped_bf16.npz")
+    weights.save_packed(path, pw)
+    pw = weights.load_packed(path)
+    assert pw.layout == layout
+    lin = WqLinear(pw)
+    wd = torch.from_numpy(weights.dequantize(pw)).double()
+    for rows in (300, 40, 5):
+        x = torch.from_numpy(rng.uniform(-1, 1, (rows, K)).astype(np.float32)).bfloat16()
+        y = lin(x.cuda())
+        assert y.dtype == torch.bfloat16
+        assert torch.allclose(y.cpu().double(), x.double() @ wd.T, rtol=1e-2, atol=1e-2)
+
+
 def test_launch_is_graph_capturable(port):
     """wqgemm_launch neither allocates nor synchronises, so a stream capture can record it: a small-M problem with the
     planner's split-K (two kernels and a workspace) and a 256-tile problem are captured into one HIP graph, replayed
