@@ -398,6 +398,12 @@ struct DeviceGemmQuantization_gfx950
             MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE, a_op, b_op, cde_op));
     }
     std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    // optional scratch for the planner's split-K of short grids (int32 partials): device_base.hpp:60-67 conventions, the
+    // caller allocates and hands it over with SetWorkSpacePointer; without it the launch runs one slice
+    size_t GetWorkSpaceSize(const BaseArgument* p_arg) const override
+    {
+        return wqgemm_workspace_bytes(&dynamic_cast<const Argument*>(p_arg)->prob);
+    }
     std::string GetTypeString() const override { return "DeviceGemmQuantization_gfx950<I8, I8, I8, Activation_Mul_Clamp>"; }
 };
 
@@ -459,6 +465,12 @@ struct DeviceGemmBiasQuantization_gfx950
             MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE, a_op, b_op, cde_op));
     }
     std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    // optional scratch for the planner's split-K of short grids (int32 partials): device_base.hpp:60-67 conventions, the
+    // caller allocates and hands it over with SetWorkSpacePointer; without it the launch runs one slice
+    size_t GetWorkSpaceSize(const BaseArgument* p_arg) const override
+    {
+        return wqgemm_workspace_bytes(&dynamic_cast<const Argument*>(p_arg)->prob);
+    }
     std::string GetTypeString() const override
     {
         return "DeviceGemmBiasQuantization_gfx950<I8, I8, I32, I8, Add_Activation_Mul_Clamp>";
