@@ -2,7 +2,8 @@
 """Benchmark of the weight-quantized GEMM hot path on MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...            (starts its own N ranks, one process per GPU, and prints rank 0's line)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks started for it)
 
 N = 1  : BASELINE config 2 -- fp16 A x packed-int4 B, per-channel fp16 scale, M = N = K = 4096.
          One step = one GEMM launch over one synthetic batch resident in HBM.
@@ -440,11 +441,16 @@ def run_splitk(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    have = torch.cuda.device_count()
+    if local >= have:
+        raise SystemExit(f"bench.py --gpus {world}: rank {rank} needs GPU {local}, this node shows {have}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", device_id=dev)
     M = N = 4096
     K = args.splitk_k
+    if M % world != 0:
+        raise SystemExit(f"bench.py --gpus {world}: M = {M} must be divisible by the number of GPUs")
     sl = splitk.partition(K, world)[rank]
     klen = sl.length
     # each rank owns its K slice of A and of the packed weights (synthetic, per-rank seed)
@@ -461,6 +467,36 @@ def run_splitk(args):
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
 
+    # ---- the step, form 1 (the product path): wqgemm_splitk_multi_step of the C ABI -- slice GEMM, ncclReduceScatter,
+    # finalize of the rank's rows, ncclAllGather, all issued by libwqgemm.so on this stream through an ncclComm_t made
+    # with RCCL's own C API (unique id from rank 0, handed round over the process group).
+    exchange, comm, comm_error = "c_abi_rccl", None, None
+    if args.exchange == "torch":
+        exchange = "torch_distributed"
+    else:
+        try:
+            from composable_kernel_amd import rccl
+            uid = torch.zeros(rccl.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(rccl.get_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            comm = rccl.comm_init_rank(world, bytes(uid.cpu().numpy().tobytes()), rank)
+        except Exception as exc:  # noqa: BLE001  (reported in the JSON line; the torch.distributed form then runs)
+            exchange, comm_error = "torch_distributed", f"{type(exc).__name__}: {exc}"
+    ok_all = torch.tensor([1 if comm is not None else 0], device=dev)
+    dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+    if int(ok_all.item()) == 0 and exchange == "c_abi_rccl":
+        exchange = "torch_distributed"  # (some rank could not make its communicator)
+
+    def multi_problem(a_t, s_t):
+        return capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), c_full.data_ptr(), M, N, klen,
+                                    lda=max(klen, 1), ldb=max(klen, 64), b_dtype=b_dtype)
+
+    p_multi = multi_problem(a, s)
+    ws_multi = torch.empty(max(capi.splitk_multi_workspace_bytes(p_multi, world), 1), dtype=torch.uint8, device=dev)
+
+    # ---- the step, form 2: the same flow with torch.distributed's collectives (splitk.splitk_gemm_step, the function
+    # the gloo tests run on CPU); timed as well, and what runs if the communicator above could not be made.
     def slice_problem(a_t, s_t):
         pg = capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), partial.data_ptr(), M, N, max(klen, 64),
                                   k_begin=0, k_end=max(klen, 64), c_dtype=capi.F32, b_dtype=b_dtype)
@@ -468,7 +504,7 @@ def run_splitk(args):
         return pg
 
     p_gemm = slice_problem(a, s)
-    cur = {"gemm": p_gemm, "scale": s}
+    cur = {"gemm": p_gemm, "scale": s, "multi": p_multi}
 
     def compute_partial(sl, partial_):
         if sl.length == 0:
@@ -477,12 +513,18 @@ def run_splitk(args):
             capi.launch(cur["gemm"], None, sp)
 
     def finalize(summed, out_rows, row0):
+        # PassThrough epilogue: no D operand, so the row offset only selects where the rows land (out_rows)
         pf = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), cur["scale"].data_ptr(), out_rows.data_ptr(),
                                   summed.shape[0], N, max(klen, 64), b_dtype=b_dtype)
         capi.reduce_finalize(pf, summed.data_ptr(), 1, sp)
 
-    def step():
+    def step_torch():
         splitk.splitk_gemm_step(compute_partial, finalize, partial, c_full, K)
+
+    def step_cabi():
+        capi.splitk_multi_step(cur["multi"], comm, rank, world, ws_multi.data_ptr(), sp)
+
+    step = step_cabi if exchange == "c_abi_rccl" else step_torch
 
     # ---- untimed check of the whole flow on exact (integer-valued) inputs: rank 0 recomputes a block of C from the
     # operands of every rank in float64 and compares bit for bit (all partial sums are exact in fp32).
@@ -493,9 +535,7 @@ def run_splitk(args):
         a_int = torch.randint(-2, 3, (M, klen), generator=g, device=dev, dtype=torch.int8).to(torch.float16)
         s_int = torch.randint(1, 3, (N,), generator=torch.Generator(device=dev).manual_seed(5), device=dev,
                               dtype=torch.int8).to(torch.float16)
-        cur["gemm"], cur["scale"] = slice_problem(a_int, s_int), s_int
-        step()
-        torch.cuda.synchronize()
+        cur["gemm"], cur["scale"], cur["multi"] = slice_problem(a_int, s_int), s_int, multi_problem(a_int, s_int)
         R, C = 8, 64
         a_blk = torch.empty((world, R, klen), dtype=torch.float16, device=dev)
         q_blk = torch.empty((world, C, klen), dtype=torch.int8, device=dev)
@@ -504,20 +544,29 @@ def run_splitk(args):
             dist.all_gather_into_tensor(q_blk, q[:C].contiguous())
         else:
             a_blk[0], q_blk[0] = a_int[:R], q[:C]
+        exp = None
         if rank == 0:
             exp = torch.zeros((R, C), dtype=torch.float64)
             for r in range(world):
                 exp += a_blk[r].cpu().double() @ (q_blk[r].cpu().double() * s_int[:C].cpu().double()[:, None]).T
-            got = c_full[:R, :C].cpu()
-            check = {"rows": R, "cols": C, "exact_match": bool(torch.equal(got, exp.to(torch.float16))),
-                     "max_abs": float(exp.abs().max())}
-        # (every rank holds the same C after the all-gather: compare rank 0's copy with the last rank's)
-        probe_c = c_full[M - 1, :C].clone()
-        if world > 1:
-            dist.broadcast(probe_c, src=world - 1)
+            check = {"rows": R, "cols": C, "max_abs": float(exp.abs().max())}
+        forms = [("c_abi_rccl", step_cabi)] if comm is not None and exchange == "c_abi_rccl" else []
+        forms.append(("torch_distributed", step_torch))
+        for name, fn in forms:
+            c_full.zero_()
+            fn()
+            torch.cuda.synchronize()
+            # (every rank holds the same C after the all-gather: compare rank 0's copy with the last rank's)
+            probe_c = c_full[M - 1, :C].clone()
+            if world > 1:
+                dist.broadcast(probe_c, src=world - 1)
+            if rank == 0:
+                check[name] = {"exact_match": bool(torch.equal(c_full[:R, :C].cpu(), exp.to(torch.float16))),
+                               "ranks_agree": bool(torch.equal(probe_c, c_full[M - 1, :C]))}
         if rank == 0:
-            check["ranks_agree"] = bool(torch.equal(probe_c, c_full[M - 1, :C]))
-        cur["gemm"], cur["scale"] = p_gemm, s
+            timed = check[exchange]
+            check["exact_match"], check["ranks_agree"] = timed["exact_match"], timed["ranks_agree"]
+        cur["gemm"], cur["scale"], cur["multi"] = p_gemm, s, p_multi
         del a_int, a_blk, q_blk
 
     for _ in range(args.warmup):
@@ -534,27 +583,52 @@ def run_splitk(args):
     for _ in range(extra):
         step()
     torch.cuda.synchronize()
+    # the timed region: barrier + synchronize on both sides of exactly `steps` steps.  The closing barrier (a small
+    # collective plus a host round trip) is inside the region and is itemised below as closing_barrier_total_ms.
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e0.record(stream)
     for _ in range(args.steps):
         step()
+    e1.record(stream)
     torch.cuda.synchronize()
+    t1 = time.perf_counter()
     dist.barrier()
     torch.cuda.synchronize()
-    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    wall = float(wall.item())
+    t2 = time.perf_counter()
+    times = torch.tensor([t2 - t0, t1 - t0, e0.elapsed_time(e1) * 1e-3], dtype=torch.float64, device=dev)
+    dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    wall, wall_steps, gpu_steps = (float(v) for v in times.tolist())
 
-    # itemise one step with events (outside the timed region)
+    # the other form of the step, timed the same way outside the headline region (for the record)
+    other_ms = None
+    if exchange == "c_abi_rccl":
+        n_other = max(1, min(args.steps, 20))
+        for _ in range(2):
+            step_torch()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(n_other):
+            step_torch()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        t_o = torch.tensor([e0.elapsed_time(e1) / n_other], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_o, op=dist.ReduceOp.MAX)
+        other_ms = float(t_o.item())
+
+    # itemise one step with events (outside the timed region): the four parts, issued separately
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     n_probe = 5
     acc = np.zeros(4)
     for _ in range(n_probe):
         ev[0].record(stream)
-        capi.launch(p_gemm, None, sp)
+        compute_partial(sl, partial)
         ev[1].record(stream)
-        summed = splitk.reduce_partials(partial, "reduce_scatter") if world > 1 else partial
+        summed = splitk.reduce_partials(partial, "reduce_scatter") if world > 1 else partial[rank * rows:(rank + 1) * rows]
         ev[2].record(stream)
         finalize(summed, c_full[rank * rows:(rank + 1) * rows], rank * rows)
         ev[3].record(stream)
@@ -587,17 +661,75 @@ def run_splitk(args):
             "config": {"workload": f"fp16A x int4B split-K GEMM M=N=4096 K={K} across {world} GPUs, "
                                    "fp32 partials, RCCL reduce-scatter + fp16 all-gather (BASELINE config 4)",
                        "M": M, "N": N, "K": K, "k_per_gpu": klen, "parallelism": f"splitk{world}",
-                       "kernel": capi.kernel_name(p_gemm)},
+                       "kernel": capi.kernel_name(p_gemm), "weights_layout": "I4_PRESHUFFLED" if b_dtype == capi.I4_PRESHUFFLED else "I4_PACKED"},
+            "exchange": {"timed": exchange,
+                         "c_abi_rccl": "wqgemm_splitk_multi_step (libwqgemm.so issues ncclReduceScatter / ncclAllGather on an ncclComm_t)",
+                         "torch_distributed": "splitk.splitk_gemm_step (reduce_scatter_tensor / all_gather_into_tensor)",
+                         "communicator_error": comm_error,
+                         "other_form_gpu_ms_per_step": other_ms},
             "splitk_check": check,
+            # wall = steps (host-timed to the end of the last step's GPU work) + the closing barrier; the GPU-side
+            # figure is the same steps between two events on the launch stream
+            "timing": {"steps_only_ms_per_step": wall_steps * 1e3 / args.steps,
+                       "gpu_events_ms_per_step": gpu_steps * 1e3 / args.steps,
+                       "closing_barrier_total_ms": (wall - wall_steps) * 1e3},
             "breakdown_ms": {"gemm": gemm_ms, "reduce_scatter_fp32": reduce_ms, "finalize": fin_ms,
-                             "all_gather_fp16": gather_ms},
+                             "all_gather_fp16": gather_ms, "sum_of_parts": gemm_ms + reduce_ms + fin_ms + gather_ms,
+                             "note": "the four parts issued one by one through torch.distributed, mean of 5"},
             "roofline": {"bound": "mfma", "achieved": kern_tflops, "peak": PEAK_FP16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": kern_tflops / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
                          "traffic_source": None, "kernel_ms": gemm_ms, "algorithmic_flops_per_launch": flops_rank,
                          "algorithmic_bytes_per_launch": algorithmic_bytes(M, N, klen, c_bytes=4)},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        from composable_kernel_amd import rccl
+        torch.cuda.synchronize()
+        rccl.comm_destroy(comm)
     dist.destroy_process_group()
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n_gpus, argv, device_count=None, run=None, out=sys.stdout, err=sys.stderr) -> int:
+    """`bench.py --gpus N` started by hand (no RANK / WORLD_SIZE in the environment): start the N ranks as fresh child
+    processes -- one per GPU, through torch.distributed.run on 127.0.0.1 -- BEFORE this process makes any GPU call, pass
+    rank 0's JSON line through to stdout and everything else to stderr, and return the children's exit status.
+    device_count / run are injection points for the CPU test."""
+    import subprocess
+    have = (device_count or torch.cuda.device_count)()  # counts devices without initialising the GPU runtime
+    if have < n_gpus:
+        print(f"bench.py --gpus {n_gpus}: needs {n_gpus} GPUs, found {have}", file=err)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver shares device memory through dmabuf only)
+    r = (run or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = 0
+    for line in (r.stdout or "").splitlines():
+        is_result = False
+        if line.startswith("{"):
+            try:
+                is_result = "metric" in json.loads(line)
+            except ValueError:
+                pass
+        if is_result and lines == 0:
+            print(line, file=out, flush=True)
+            lines += 1
+        else:
+            print(line, file=err)
+    if r.stderr:
+        print(r.stderr, file=err, end="")
+    if r.returncode == 0 and lines != 1:
+        print(f"bench.py --gpus {n_gpus}: the ranks exited cleanly without a result line", file=err)
+        return 1
+    return r.returncode
 
 
 def main():
@@ -608,16 +740,24 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the baseline")
     ap.add_argument("--splitk-k", type=int, default=65536)
-    ap.add_argument("--config", choices=("C1", "C2", "C3", "C5"), default="C2",
-                    help="1-GPU workload: C2 (default) is the configuration the metric is quoted on; the others are "
-                         "the remaining single-GPU BASELINE configurations, each with its own CPU baseline")
+    ap.add_argument("--config", choices=("C1", "C2", "C3", "C4", "C5"), default="C2",
+                    help="1-GPU workload: C2 (default) is the configuration the metric is quoted on; C1, C3, C5 are the "
+                         "remaining single-GPU BASELINE configurations, each with its own CPU baseline; C4 runs the "
+                         "multi-GPU split-K flow (what --gpus N > 1 runs) on --gpus ranks, also on one")
     ap.add_argument("--ramp-launches", type=int, default=1500,
                     help="extra untimed launches before the timed region so the GPU clocks have settled")
+    ap.add_argument("--exchange", choices=("c_abi", "torch"), default="c_abi",
+                    help="N > 1: which form of the split-K step is timed -- the C ABI's wqgemm_splitk_multi_step over an "
+                         "ncclComm_t (default) or the same flow through torch.distributed's collectives")
     args = ap.parse_args()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (args.gpus > 1 or args.config == "C4") and not launched:
+        # started by hand: this process only starts the ranks (no GPU call is made here, before or after)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (run it through gpurun)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.config == "C4":
         run_splitk(args)
     else:
         run_single(args)

@@ -261,7 +261,11 @@ __device__ __forceinline__ f2_t fast_gelu2(f2_t x)
     return x * f2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
-__device__ __forceinline__ float load_d_as_f32(const void* d, int idx, int c_dtype)
+// Flat index of element (i, j) of a D operand with leading dimension ld, in 64 bits: full (M, N) D tensors of problems
+// whose operands exceed 2 GiB have indices beyond INT_MAX.
+__device__ __forceinline__ size_t d_at(int i, int ld, int j) { return (size_t)i * (size_t)ld + (size_t)j; }
+
+__device__ __forceinline__ float load_d_as_f32(const void* d, size_t idx, int c_dtype)
 {
     // MultiplyAddFastGelu operands have the output's 16-bit type
     const uint16_t bits = ((const uint16_t*)d)[idx];
@@ -298,26 +302,26 @@ __device__ __forceinline__ float apply_epilogue(const EpilogueArgs& e, float x, 
     case 1: return fast_gelu(x);
     case 2: {
         // element_wise_operation.hpp:277-295: FastGelu(c * d0 + d1), separate multiply and add
-        const float t = x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
-        return fast_gelu(t + load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
+        const float t = x * load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype);
+        return fast_gelu(t + load_d_as_f32(e.d1, d_at(m, e.ldd1, n), e.c_dtype));
     }
     case 3: {
         // element_wise_operation.hpp:252-275: c * d0 * d1 left to right
-        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
-        return t * ((const float*)e.d1)[m + n * e.ldd1];
+        const float t = x * ((const float*)e.d0)[d_at(m, e.ldd0, n)];
+        return t * ((const float*)e.d1)[d_at(n, e.ldd1, m)];
     }
     case 4: {
-        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
-        return fast_gelu(t * ((const float*)e.d1)[m + n * e.ldd1]);
+        const float t = x * ((const float*)e.d0)[d_at(m, e.ldd0, n)];
+        return fast_gelu(t * ((const float*)e.d1)[d_at(n, e.ldd1, m)]);
     }
     // binary_element_wise_operation.hpp: Add :78-85, AddFastGelu :511-522, Multiply (float x bhalf), MultiplyFastGelu
     // :578-590 -- the second operand is d0[n] of the output's 16-bit type
-    case 6: return x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
-    case 7: return fast_gelu(x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
-    case 8: return x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
-    case 9: return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
+    case 6: return x + load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype);
+    case 7: return fast_gelu(x + load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype));
+    case 8: return x * load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype);
+    case 9: return fast_gelu(x * load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype));
     case 13:
-        return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype), load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
+        return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype), load_d_as_f32(e.d1, d_at(m, e.ldd1, n), e.c_dtype));
     case 14: return convert_bf16_rtn_bits(x);
     default: return x;
     }
@@ -331,29 +335,29 @@ __device__ __forceinline__ float apply_epilogue_k(const EpilogueArgs& e, float x
         return fast_gelu(x);
     else if constexpr(KIND == 2)
     {
-        const float t = x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
-        return fast_gelu(t + load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
+        const float t = x * load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype);
+        return fast_gelu(t + load_d_as_f32(e.d1, d_at(m, e.ldd1, n), e.c_dtype));
     }
     else if constexpr(KIND == 3)
     {
-        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
-        return t * ((const float*)e.d1)[m + n * e.ldd1];
+        const float t = x * ((const float*)e.d0)[d_at(m, e.ldd0, n)];
+        return t * ((const float*)e.d1)[d_at(n, e.ldd1, m)];
     }
     else if constexpr(KIND == 4)
     {
-        const float t = x * ((const float*)e.d0)[m * e.ldd0 + n];
-        return fast_gelu(t * ((const float*)e.d1)[m + n * e.ldd1]);
+        const float t = x * ((const float*)e.d0)[d_at(m, e.ldd0, n)];
+        return fast_gelu(t * ((const float*)e.d1)[d_at(n, e.ldd1, m)]);
     }
     else if constexpr(KIND == 6)
-        return x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
+        return x + load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype);
     else if constexpr(KIND == 7)
-        return fast_gelu(x + load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
+        return fast_gelu(x + load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype));
     else if constexpr(KIND == 8)
-        return x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype);
+        return x * load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype);
     else if constexpr(KIND == 9)
-        return fast_gelu(x * load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype));
+        return fast_gelu(x * load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype));
     else if constexpr(KIND == 13)
-        return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, m * e.ldd0 + n, e.c_dtype), load_d_as_f32(e.d1, m * e.ldd1 + n, e.c_dtype));
+        return multiply_add_bf16_bits(x, load_d_as_f32(e.d0, d_at(m, e.ldd0, n), e.c_dtype), load_d_as_f32(e.d1, d_at(m, e.ldd1, n), e.c_dtype));
     else if constexpr(KIND == 14)
         return convert_bf16_rtn_bits(x);
     else
@@ -376,7 +380,7 @@ __device__ __forceinline__ f4_t apply_epilogue4(const EpilogueArgs& e, f4_t v, i
     f2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
     if constexpr(KIND == 2 || (KIND >= 6 && KIND <= 9))
     {
-        const int i0 = m * e.ldd0 + n;
+        const size_t i0 = d_at(m, e.ldd0, n);
         const f2_t d0l = {load_d_as_f32(e.d0, i0, e.c_dtype), load_d_as_f32(e.d0, i0 + 1, e.c_dtype)};
         const f2_t d0h = {load_d_as_f32(e.d0, i0 + 2, e.c_dtype), load_d_as_f32(e.d0, i0 + 3, e.c_dtype)};
         if constexpr(KIND == 6 || KIND == 7)
@@ -385,17 +389,17 @@ __device__ __forceinline__ f4_t apply_epilogue4(const EpilogueArgs& e, f4_t v, i
             lo = lo * d0l, hi = hi * d0h;
         if constexpr(KIND == 2)
         {
-            const int i1 = m * e.ldd1 + n;
+            const size_t i1 = d_at(m, e.ldd1, n);
             lo = lo + f2_t{load_d_as_f32(e.d1, i1, e.c_dtype), load_d_as_f32(e.d1, i1 + 1, e.c_dtype)};
             hi = hi + f2_t{load_d_as_f32(e.d1, i1 + 2, e.c_dtype), load_d_as_f32(e.d1, i1 + 3, e.c_dtype)};
         }
     }
     else if constexpr(KIND == 3 || KIND == 4)
     {
-        const float* d0 = (const float*)e.d0 + (m * e.ldd0 + n);
-        const float* d1 = (const float*)e.d1 + (m + n * e.ldd1);
+        const float* d0 = (const float*)e.d0 + d_at(m, e.ldd0, n);
+        const float* d1 = (const float*)e.d1 + d_at(n, e.ldd1, m);
         lo = lo * f2_t{d0[0], d0[1]}, hi = hi * f2_t{d0[2], d0[3]};
-        lo = lo * f2_t{d1[0], d1[e.ldd1]}, hi = hi * f2_t{d1[2 * e.ldd1], d1[3 * e.ldd1]};
+        lo = lo * f2_t{d1[0], d1[(size_t)e.ldd1]}, hi = hi * f2_t{d1[2 * (size_t)e.ldd1], d1[3 * (size_t)e.ldd1]};
     }
     if constexpr(KIND == 1 || KIND == 2 || KIND == 4 || KIND == 7 || KIND == 9)
         lo = fast_gelu2(lo), hi = fast_gelu2(hi);

@@ -1,6 +1,7 @@
 // One translation unit per (activation type, weight format) pair of the 256-tile kernel family:
 // compiled with -DWQ_INST_AK=<0|1> -DWQ_INST_BK=<0|1|2>.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include "wqgemm.h"
 #include "wq_gemm_256.h"
@@ -16,7 +17,7 @@ template <int AK, int BKIND, int WM, int SCHED, bool STAMP, bool GROUPED = false
 int launch_v(const GemmParams& gp, dim3 grid, hipStream_t s)
 {
     // more than 64 KiB of dynamic LDS must be opted into once per device
-    static bool opted_in[64] = {};
+    static std::atomic<bool> opted_in[64];
     int dev                  = 0;
     if(hipGetDevice(&dev) != hipSuccess)
         return WQ_ERR_HIP;

@@ -1,5 +1,6 @@
 // Translation unit of the fp8 x packed-int4 256-tile kernel.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include "wqgemm.h"
 #include "wq_gemm_256_f8.h"
@@ -11,7 +12,7 @@ namespace {
 
 // more than 64 KiB of dynamic LDS must be opted into once per device
 template <typename K>
-int launch_big_lds(K kernel, int lds_bytes, bool (&opted_in)[64], const GemmParams& gp, dim3 grid, hipStream_t s)
+int launch_big_lds(K kernel, int lds_bytes, std::atomic<bool> (&opted_in)[64], const GemmParams& gp, dim3 grid, hipStream_t s)
 {
     int dev = 0;
     if(hipGetDevice(&dev) != hipSuccess)
@@ -30,7 +31,7 @@ int launch_big_lds(K kernel, int lds_bytes, bool (&opted_in)[64], const GemmPara
 
 int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant)
 {
-    static bool opted_s[64] = {}, opted_pp[64] = {}, opted_stamp[64] = {};
+    static std::atomic<bool> opted_s[64], opted_pp[64], opted_stamp[64];
     if(gp.dbg) // diagnostic: the stamped build of the ping-pong form
         return launch_big_lds(wq_gemm_f8_mfma_256_pp<true>, Mfma256F8::LDS_BYTES, opted_stamp, gp, grid, s);
     if(variant & WQ_FLAG_PINGPONG)

@@ -1,5 +1,6 @@
 // Translation unit of the 32x32x16-MFMA variant of the 256-tile kernel (16-bit activations x packed int4).
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include "wqgemm.h"
 #include "wq_gemm_256_w32.h"
@@ -12,7 +13,7 @@ template <int AK, bool STAMP>
 int launch_v(const GemmParams& gp, dim3 grid, hipStream_t s)
 {
     // more than 64 KiB of dynamic LDS must be opted into once per device
-    static bool opted_in[64] = {};
+    static std::atomic<bool> opted_in[64];
     int dev                  = 0;
     if(hipGetDevice(&dev) != hipSuccess)
         return WQ_ERR_HIP;

@@ -122,6 +122,13 @@ int check_fp_epilogue(const wqgemm_problem* p)
     }
     if(p->ldd0 < 0 || p->ldd1 < 0)
         return fail(WQ_ERR_INVALID, "ldd0 and ldd1 must be 0 (broadcast) or a positive leading dimension");
+    // A full D tensor whose leading dimension is shorter than its rows (columns for MultiplyMultiply's column-major d1)
+    // would alias: refused rather than read as given.
+    const bool mm = p->epilogue == WQ_EPI_MULTIPLY_MULTIPLY || p->epilogue == WQ_EPI_MULTIPLY_MULTIPLY_FASTGELU;
+    if(p->ldd0 > 0 && p->ldd0 < p->N)
+        return fail(WQ_ERR_INVALID, "ldd0 = %d is shorter than a row of d0 (N = %d)", p->ldd0, p->N);
+    if(p->ldd1 > 0 && p->ldd1 < (mm ? p->M : p->N))
+        return fail(WQ_ERR_INVALID, "ldd1 = %d is shorter than a %s of d1 (%d)", p->ldd1, mm ? "column" : "row", mm ? p->M : p->N);
     return WQ_OK;
 }
 
@@ -764,7 +771,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.kind    = p->epilogue;
         gp.bias    = (const int32_t*)p->d0;
         gp.partial = nullptr, gp.k_tiles_per_z = 0;
-        static bool opted_in[64] = {}; // more than 64 KiB of dynamic LDS must be opted into once per device
+        static std::atomic<bool> opted_in[64]; // more than 64 KiB of dynamic LDS must be opted into once per device
         int dev                  = 0;
         WQ_HIP(hipGetDevice(&dev));
         if(dev >= 0 && dev < 64 && !opted_in[dev])
@@ -879,28 +886,30 @@ struct RcclApi
     int (*reduce_scatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t)          = nullptr;
     const char* (*error_string)(int)                                                = nullptr;
-    bool tried = false, ok = false;
+    bool ok = false;
 };
-RcclApi& rccl()
+// Built once, on first use, by whichever thread gets there first (function-local static: the C++ runtime serialises
+// the initialisation and publishes the finished table).
+const RcclApi& rccl()
 {
-    static RcclApi api;
-    if(api.tried)
-        return api;
-    api.tried  = true;
-    void* h = nullptr;
-    for(const char* name : {"librccl.so.1", "librccl.so"})
-        if((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)))
-            break;
-    if(!h)
-        for(const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+    static const RcclApi api = [] {
+        RcclApi t;
+        void* h = nullptr;
+        for(const char* name : {"librccl.so.1", "librccl.so"})
+            if((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)))
                 break;
-    if(!h)
-        return api;
-    api.reduce_scatter = (decltype(api.reduce_scatter))dlsym(h, "ncclReduceScatter");
-    api.all_gather     = (decltype(api.all_gather))dlsym(h, "ncclAllGather");
-    api.error_string   = (decltype(api.error_string))dlsym(h, "ncclGetErrorString");
-    api.ok             = api.reduce_scatter && api.all_gather;
+        if(!h)
+            for(const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+                    break;
+        if(!h)
+            return t;
+        t.reduce_scatter = (decltype(t.reduce_scatter))dlsym(h, "ncclReduceScatter");
+        t.all_gather     = (decltype(t.all_gather))dlsym(h, "ncclAllGather");
+        t.error_string   = (decltype(t.error_string))dlsym(h, "ncclGetErrorString");
+        t.ok             = t.reduce_scatter && t.all_gather;
+        return t;
+    }();
     return api;
 }
 constexpr int kNcclInt8 = 0, kNcclFloat32 = 7, kNcclSum = 0; // rccl.h: ncclDataType_t / ncclRedOp_t
@@ -932,11 +941,8 @@ int wqgemm_is_supported(const wqgemm_problem* p)
     return make_plan(p, plan) == WQ_OK ? 1 : 0;
 }
 
-size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
+static size_t plan_workspace_bytes(const wqgemm_problem* p, const Plan& plan)
 {
-    Plan plan;
-    if(make_plan(p, plan) != WQ_OK)
-        return 0;
     if(plan.partial && !plan.to_c)
         return (size_t)plan.k_batch * p->M * p->N * sizeof(float) + (plan.via_colb ? (size_t)p->K * p->N : 0);
     if(plan.via_f16)
@@ -946,13 +952,17 @@ size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
     return 0;
 }
 
-int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
+size_t wqgemm_workspace_bytes(const wqgemm_problem* p)
 {
     Plan plan;
-    const int rc = make_plan(p, plan, workspace != nullptr);
-    if(rc != WQ_OK)
-        return rc;
-    hipStream_t s = (hipStream_t)stream;
+    if(make_plan(p, plan) != WQ_OK)
+        return 0;
+    return plan_workspace_bytes(p, plan);
+}
+
+// Run a plan made for `workspace != nullptr` (or without one: every optional use of it is dropped first).
+static int launch_planned(const wqgemm_problem* p, Plan plan, void* workspace, hipStream_t s)
+{
     if(plan.auto_split && !workspace)
     {
         // the planner's own split-K is an optimisation: without a workspace the kernel runs the whole K range as
@@ -971,6 +981,9 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     {
         plan.via_f16 = plan.via_colb = false; // no room for the re-laid-out operand: the general kernel takes it as it is
         plan.route                   = ROUTE_GENERIC;
+        if((p->M + 15) / 16 > 65535)
+            return fail(WQ_ERR_UNSUPPORTED, "the general kernel takes at most 1048560 rows (M = %d); with a workspace of %zu bytes "
+                        "the matrix-core kernels run this problem", p->M, wqgemm_workspace_bytes(p));
     }
     const int rm = launch_main(p, plan, workspace, s);
     if(rm != WQ_OK)
@@ -978,6 +991,15 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
     if(plan.partial && !plan.to_c)
         return launch_reduce(p, (const float*)workspace, plan.k_batch, s);
     return WQ_OK;
+}
+
+int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream)
+{
+    Plan plan;
+    const int rc = make_plan(p, plan, workspace != nullptr);
+    if(rc != WQ_OK)
+        return rc;
+    return launch_planned(p, plan, workspace, (hipStream_t)stream);
 }
 
 // Device address of this GPU's copy of `scratch`, looked up once per device with that device current.
@@ -1004,9 +1026,9 @@ static int noalloc_scratch(void** out)
 int wqgemm_launch_noalloc(const wqgemm_problem* p, void* stream)
 {
     Plan plan;
-    if(const int rc = make_plan(p, plan); rc != WQ_OK)
+    if(const int rc = make_plan(p, plan, true); rc != WQ_OK)
         return rc;
-    const size_t need = wqgemm_workspace_bytes(p);
+    const size_t need = plan_workspace_bytes(p, plan);
     if(need > WQGEMM_NOALLOC_SCRATCH_BYTES)
     {
         if(plan.partial && !plan.auto_split)
@@ -1019,7 +1041,9 @@ int wqgemm_launch_noalloc(const wqgemm_problem* p, void* stream)
     if(need != 0)
         if(const int rc = noalloc_scratch(&ws); rc != WQ_OK)
             return rc;
-    return wqgemm_launch(p, ws, stream);
+    if(!ws) // (nothing to hold: the plan for "no workspace" can differ from the one made above)
+        return wqgemm_launch(p, nullptr, stream);
+    return launch_planned(p, plan, ws, (hipStream_t)stream);
 }
 
 int wqgemm_run_timed(const wqgemm_problem* p, void* workspace, void* stream, int cold_iters,
@@ -1356,7 +1380,7 @@ int wqgemm_splitk_multi_step(const wqgemm_problem* p, void* nccl_comm, int32_t r
     const float* summed = partial + (size_t)row0 * p->N;
     if(nccl_comm)
     {
-        RcclApi& api = rccl();
+        const RcclApi& api = rccl();
         if(!api.ok)
             return fail(WQ_ERR_HIP, "splitk_multi_step: librccl.so.1 (ncclReduceScatter / ncclAllGather) could not be loaded");
         const int rc = api.reduce_scatter(partial, sum_rows, (size_t)rows * p->N, kNcclFloat32, kNcclSum, nccl_comm, s);
@@ -1380,7 +1404,7 @@ int wqgemm_splitk_multi_step(const wqgemm_problem* p, void* nccl_comm, int32_t r
     // 4. every rank receives every row block
     if(nccl_comm)
     {
-        RcclApi& api       = rccl();
+        const RcclApi& api = rccl();
         const size_t bytes = (size_t)rows * p->N * out_elt_bytes(p->c_dtype);
         const int rc       = api.all_gather((const uint8_t*)p->c + (size_t)rank * bytes, p->c, bytes, kNcclInt8, nccl_comm, s);
         if(rc != 0)

@@ -196,7 +196,9 @@ int wqgemm_launch(const wqgemm_problem* p, void* workspace, void* stream);
  * and launches nothing; an OPTIONAL workspace use that does not fit is dropped exactly as wqgemm_launch drops it
  * for a NULL workspace.  Results are those of wqgemm_launch with a workspace, bit for bit.  All calls on one GPU
  * share that GPU's scratch: nothing in it needs initialising (each launch writes every byte it later reads), but two
- * calls that overlap on one GPU -- different streams or threads -- race on it; serialise them. */
+ * calls that overlap on one GPU -- different streams or threads -- race on it; serialise them.  The first call on a
+ * device that uses the scratch looks its address up (hipGetSymbolAddress, once per device): make one such call
+ * outside stream capture before capturing. */
 #define WQGEMM_NOALLOC_SCRATCH_BYTES (64u << 20)
 int wqgemm_launch_noalloc(const wqgemm_problem* p, void* stream);
 

@@ -19,8 +19,9 @@ EX = os.path.join(ROOT, "examples")
 
 
 def _run(path, *args):
-    if not os.path.exists(path):
-        pytest.skip(f"{os.path.basename(path)} not built")
+    # a missing binary is a failure, not a skip: the boundary suite must never pass by not running
+    assert os.path.exists(path), (f"{os.path.relpath(path, ROOT)} is not built: run `make -C examples` (and, where the CK tree "
+                                  "is mounted, `make -C examples dropin`) before the GPU tests")
     r = subprocess.run([path, *map(str, args)], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     return r

@@ -79,3 +79,44 @@ def test_weights_above_2_gib(port, M, kernel):
     q_tail = np.ascontiguousarray(b_t[N - tail:].cpu().numpy())
     exp = port.fpAintB_gemm_f16(np.ascontiguousarray(a[:rows]), q_tail, s[N - tail:], rows, tail, K, K, K, tail).reshape(rows, tail)
     check_err(bits_to_f32(got[:rows], capi.F16), bits_to_f32(exp, capi.F16), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("flag,kb", [(capi.FLAG_TILE_256, 1), (capi.FLAG_TILE_128, 1), (capi.FLAG_TILE_128, 2), (capi.FLAG_GENERIC, 1)])
+def test_full_d_matrix_indexed_beyond_int32(flag, kb):
+    """A full (M, N) D operand whose flat index m * ldd0 + n passes 2^31: the epilogues (tile kernels, the general kernel
+    and the split-K reduce) must index it with 64 bits.  Rows above the mark equal a separate launch over those rows
+    alone with the D pointer moved to their first row; Add with an integer-valued D is exact, so the comparison is too."""
+    M, N, K, ldd, tail = (1 << 18) + 512, 512, 128, 8192, 512
+    if flag == capi.FLAG_GENERIC:
+        M = (1 << 18) + 512          # (the general kernel's grid covers it: 16 rows per block)
+    assert (M - tail) * ldd > (1 << 31)
+    gen = torch.Generator(device="cuda").manual_seed(41)
+    q = torch.randint(-8, 8, (N, K), dtype=torch.int8, device="cuda", generator=gen)
+    bp = torch.empty((N, K // 2), dtype=torch.uint8, device="cuda")
+    capi.pack_int4(q.data_ptr(), K, K, N, bp.data_ptr(), K // 2, torch.cuda.current_stream().cuda_stream)
+    s_t = torch.ones((N,), dtype=torch.float16, device="cuda")
+    a_t = torch.randint(-2, 3, (M, K), device="cuda", generator=gen).half()
+    d_t = torch.zeros((M, ldd), dtype=torch.float16, device="cuda")
+    d_t[:, :N] = torch.randint(-64, 65, (M, N), device="cuda", generator=gen).half()
+    c_t = torch.full((M, N), 0x7BFF, dtype=torch.int16, device="cuda")
+
+    def run(a, d, c, rows):
+        p = capi.fpAintB_problem(a.data_ptr(), bp.data_ptr(), s_t.data_ptr(), c.data_ptr(), rows, N, K, epilogue=capi.EPI_ADD,
+                                 d0=d.data_ptr(), ldd0=ldd, flags=flag, k_batch=kb)
+        assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
+        ws = torch.empty(max(capi.workspace_bytes(p), 1), dtype=torch.uint8, device="cuda")
+        capi.launch(p, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+
+    run(a_t, d_t, c_t, M)
+    r0 = M - tail
+    c_s = torch.full((tail, N), 0x7BFF, dtype=torch.int16, device="cuda")
+    run(a_t[r0:], d_t[r0:], c_s, tail)
+    assert torch.equal(c_t[r0:], c_s)
+    # and against plain arithmetic: every sum is a small integer, exact in fp16
+    exp = (a_t[r0:].float() @ q.float().T + d_t[r0:, :N].float()).half()
+    assert torch.equal(c_s.view(torch.float16), exp)
+    # a leading dimension shorter than a row is refused
+    bad = capi.fpAintB_problem(a_t.data_ptr(), bp.data_ptr(), s_t.data_ptr(), c_t.data_ptr(), 256, N, K, epilogue=capi.EPI_ADD,
+                               d0=d_t.data_ptr(), ldd0=N - 8)
+    assert not capi.is_supported(bad)

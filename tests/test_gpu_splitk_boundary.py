@@ -142,23 +142,6 @@ def test_rotating_timed_run_matches_plain():
         capi.run_timed_rotating(p, ws.data_ptr(), st, 1, 3, 65)
 
 
-def _rccl_single_rank_comm():
-    """A one-rank RCCL communicator made through the C API of the copy torch ships (what a C++ caller would hold)."""
-    import ctypes as C
-    import os
-    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
-
-    class UniqueId(C.Structure):
-        _fields_ = [("internal", C.c_char * 128)]
-
-    uid = UniqueId()
-    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
-    comm = C.c_void_p()
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
-    return rccl, comm
-
-
 def test_splitk_multi_step_c_abi(port):
     """wqgemm_splitk_multi_step, the C-ABI form of the multi-GPU flow: (a) through a real one-rank RCCL communicator
     (reduce-scatter and all-gather are issued) the result is the single-pass kernel's, bit for bit; (b) without
@@ -177,15 +160,16 @@ def test_splitk_multi_step_c_abi(port):
     capi.launch(p_ref, None, st)
     torch.cuda.synchronize()
 
-    rccl, comm = _rccl_single_rank_comm()
+    from composable_kernel_amd import rccl
+    comm = rccl.comm_init_rank(1, rccl.get_unique_id(), 0)
     c = torch.zeros((M, N), dtype=torch.int16, device="cuda")
     p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), s_t.data_ptr(), c.data_ptr(), M, N, K, flags=capi.FLAG_TILE_256)
     ws = torch.empty(capi.splitk_multi_workspace_bytes(p, 1), dtype=torch.uint8, device="cuda")
     assert ws.numel() == 2 * M * N * 4
-    capi.splitk_multi_step(p, comm.value, 0, 1, ws.data_ptr(), st)
+    capi.splitk_multi_step(p, comm, 0, 1, ws.data_ptr(), st)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(host_u16(c), host_u16(c_ref))
-    assert rccl.ncclCommDestroy(comm) == 0
+    rccl.comm_destroy(comm)
 
     # (b) two ranks rehearsed in one process, MultiplyMultiply with per-row d1: fp8 activations
     a8 = dev(rng.choice(np.array([0x00, 0x38, 0x40, 0xB8, 0xC0], np.uint8), (M, K)))

@@ -67,3 +67,56 @@ def test_noalloc_matches_workspace_launch_twice_then_limit():
     assert capi.lib.wqgemm_launch_noalloc(C.byref(big), None) == capi.ERR_WORKSPACE
     assert b"built-in scratch" in capi.lib.wqgemm_last_error()
     torch.cuda.synchronize()
+
+
+def test_noalloc_optional_scratch_dropped_and_no_scratch_needed():
+    """The two branches that use no scratch: an OPTIONAL workspace use larger than the built-in scratch is dropped exactly
+    as wqgemm_launch drops it for a NULL workspace (here: the K-contiguous copy of row-major weights), and a problem that needs no workspace at all goes straight through.  Same bits as the plain launch."""
+    rng = np.random.default_rng(77)
+    st = torch.cuda.current_stream().cuda_stream
+    # row-major 8-bit weights of 8192 x 8448 bytes: their K-contiguous copy (66 MiB) is an optional workspace use that does
+    # not fit the 64 MiB scratch, so both entry points run the general kernel on the weights as they are
+    M, N, K = 32, 8448, 8192
+    a_t = dev(f16_bits(rng.integers(-2, 3, (M, K)).astype(np.float32)))
+    brow = dev(rng.integers(-8, 8, (K, N)).astype(np.int8))
+    s_t = dev(f16_bits(rng.integers(1, 3, N).astype(np.float32)))
+
+    def prob(c_t):
+        return capi.fpAintB_problem(a_t.data_ptr(), brow.data_ptr(), s_t.data_ptr(), c_t.data_ptr(), M, N, K, b_dtype=capi.I8,
+                                    b_layout=capi.ROW_MAJOR, ldb=N)
+
+    outs = []
+    for which in range(2):
+        c_t = torch.full((M, N), 0x7BFF, dtype=torch.int16, device="cuda")
+        p = prob(c_t)
+        assert capi.workspace_bytes(p) == K * N > capi.NOALLOC_SCRATCH_BYTES
+        if which == 0:
+            capi.launch(p, None, st)
+        else:
+            capi.launch_noalloc(p, st)
+        torch.cuda.synchronize()
+        outs.append(host_u16(c_t).copy())
+    np.testing.assert_array_equal(outs[1], outs[0])
+    # with the workspace the matrix-core route runs; on these integer inputs (exact sums) it gives the same bits too
+    c_t = torch.full((M, N), 0x7BFF, dtype=torch.int16, device="cuda")
+    p = prob(c_t)
+    ws = torch.empty(capi.workspace_bytes(p), dtype=torch.uint8, device="cuda")
+    capi.launch(p, ws.data_ptr(), st)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host_u16(c_t), outs[0])
+    # need == 0: one full wave of 256-tiles, no workspace use of any kind
+    M, N, K = 1024, 1024, 512
+    a_t = dev(f16_bits(rng.uniform(-1, 1, (M, K))))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    b_t = pack_on_device(q, K, N)
+    s_t = dev(f16_bits(rng.uniform(2.0 ** -8, 2.0 ** -4, N)))
+    outs = []
+    for which in range(2):
+        c_t = torch.full((M, N), 0x7BFF, dtype=torch.int16, device="cuda")
+        p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), s_t.data_ptr(), c_t.data_ptr(), M, N, K, flags=capi.FLAG_TILE_256)
+        assert capi.workspace_bytes(p) == 0
+        (capi.launch_noalloc(p, st) if which else capi.launch(p, None, st))
+        torch.cuda.synchronize()
+        outs.append(host_u16(c_t).copy())
+    np.testing.assert_array_equal(outs[1], outs[0])
+    assert (outs[0] != 0x7BFF).all()
