@@ -1,8 +1,10 @@
 // 256 x 256 x 128 MFMA kernel for fp8 activations x packed int4 weights (gfx950), software-pipelined form.
 //
 // Same arithmetic, operand formats and epilogue as the ping-pong form wq_gemm_f8_mfma_256_pp (wq_gemm_256_f8.h): E4M3 activation bytes
-// and weights converted in registers to E5M2 feed v_mfma_scale_f32_16x16x128_f8f6f4; FNUZ bytes run with a 2^-1
-// block scale.  What differs is how a wave's loads meet its MFMAs:
+// and weights converted in registers to E5M2 feed the matrix core's 16x16x128 f8f6f4 instruction -- here in its plain
+// form v_mfma_f32_16x16x128_f8f6f4 (no block scales: measured 2 - 3 % faster than v_mfma_scale_*, whose scale-load half
+// takes an issue slot of its own); FNUZ bytes, which the matrix core reads as twice their value, get their 2^-1 on the
+// accumulators after the K loop (exact).  What differs is how a wave's loads meet its MFMAs:
 //
 //   * no load sections: every wave streams its own operands between its own MFMAs.  The activation fragments of
 //     row block mt + LEAD are fetched from LDS while row block mt is multiplied (a rolling window of LEAD + 1
@@ -40,7 +42,16 @@ struct Mfma256F8S
     static constexpr int LEAD        = 3;                 // row blocks between a fragment's fetch and its MFMAs (window of 4 divides 16)
 };
 
-__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p)
+// PROBE = 0 is the product kernel.  Other values exist only for the timing diagnostics in tools/f8_probe.hip: each bit
+// removes one ingredient of the K loop (results are then meaningless; only the time is of interest).
+//   1 no weight conversion   2 no fragment reads from LDS   4 no global loads   8 no barrier   16 no MFMA
+//   32 zero E8M0 scale operands (instruction-selection check)
+//   64 LDS-DMA pieces of a tile issued four row blocks apart instead of back to back behind the barrier
+//   128, 256, 384: other instruction orders inside a row block
+//   512 fragment reads issued but never consumed (the MFMAs keep the fragments of the prologue)
+//   1024 no LDS-DMA in the loop (weight loads stay)   2048 no weight loads in the loop (LDS-DMA stays)
+template <int PROBE>
+__device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 {
     using T = Mfma256F8S;
     constexpr int MT = 16, NT = 2, LEAD = T::LEAD, WIN = LEAD + 1;
@@ -65,8 +76,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
 
     I4F8Consts i4c;
     i4c.init();
-    const int scale_w = 0x7F7F7F7F; // weights: 2^0
-    const int scale_a = p.a_scale;  // activations: 2^0 (E4M3FN bytes) or 2^-1 (FNUZ bytes)
+    [[maybe_unused]] const int scale_w = 0x7F7F7F7F; // (diagnostic variant 32 only) weights: 2^0
+    [[maybe_unused]] const int scale_a = p.a_scale;  // (diagnostic variant 32 only) activations: 2^0 (E4M3FN) or 2^-1 (FNUZ)
 
     // Activations: buffer resource ending with the last byte of row M - 1 (rows a partial last row tile has past M
     // are out of range: answered without touching memory, results never stored); a running scalar offset per
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
         a_off[h] = fr * 128 + (((2 * fq + h) ^ f8_a_swz(fr)) << 4);
 
     i8v_t af[WIN];     // rolling window of activation fragments
+    i8v_t afd[WIN];    // (diagnostic variant 512 only: where unconsumed reads land)
     u4_t raw[2][NT];   // packed weights of tiles t+1 / t+2 (by tile parity)
     i8v_t wf[2][NT];   // converted weights of tiles t / t+1 (by tile parity)
 
@@ -132,6 +144,15 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
         const u4_t hi     = *(const u4_t*)(sa + a_off[1]);
         af[w][0] = lo[0], af[w][1] = lo[1], af[w][2] = lo[2], af[w][3] = lo[3];
         af[w][4] = hi[0], af[w][5] = hi[1], af[w][6] = hi[2], af[w][7] = hi[3];
+    };
+    auto read_a_unused = [&](int slot, int mt, auto win) __attribute__((always_inline)) {
+        constexpr int w   = decltype(win)::value;
+        const uint8_t* sa = lds + slot * T::A_TILE + mt * 16 * 128;
+        u4_t lo, hi;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(lo) : "v"((uint32_t)(uintptr_t)(sa + a_off[0])));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(hi) : "v"((uint32_t)(uintptr_t)(sa + a_off[1])));
+        afd[w][0] = lo[0], afd[w][1] = lo[1], afd[w][2] = lo[2], afd[w][3] = lo[3];
+        afd[w][4] = hi[0], afd[w][5] = hi[1], afd[w][6] = hi[2], afd[w][7] = hi[3];
     };
     // conversion piece j (0..7) = 32-bit word j % 4 of raw[.][j / 4] -> registers 2 (j % 4), +1 of out[j / 4]
     auto convert_piece = [&](i8v_t(&out)[NT], const u4_t(&in)[NT], auto piece) __attribute__((always_inline)) {
@@ -161,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
     }
 
     // ---- prologue: A(0), B(0), A(1), B(1), A(2); tile 0 complete and converted, first LEAD fragments fetched ----
+    constexpr bool SPREAD = (PROBE & 64) != 0;
 #pragma unroll
     for(int i = 0; i < T::A_DMA; ++i)
         dma_a(a_rsrc, 0, i);
@@ -168,15 +190,27 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
     {
         const __amdgpu_buffer_rsrc_t a1 = ntiles > 1 ? a_rsrc : null_rsrc, b1 = ntiles > 1 ? b_rsrc : null_rsrc;
         const __amdgpu_buffer_rsrc_t a2 = ntiles > 2 ? a_rsrc : null_rsrc;
+        if constexpr(SPREAD)
+        {
+            // (the weights first: tile 0 waits for them with the loop's own count, which needs four operations behind them)
+            load_b(b1, raw[1], 1);
 #pragma unroll
-        for(int i = 0; i < T::A_DMA; ++i)
-            dma_a(a1, 1, i);
-        load_b(b1, raw[1], 1);
+            for(int i = 0; i < T::A_DMA; ++i)
+                dma_a(a1, 1, i);
+            dma_a(a2, 2, 0); // pieces 1 .. 3 of A(2) follow inside tile 0
+        }
+        else
+        {
 #pragma unroll
-        for(int i = 0; i < T::A_DMA; ++i)
-            dma_a(a2, 2, i);
+            for(int i = 0; i < T::A_DMA; ++i)
+                dma_a(a1, 1, i);
+            load_b(b1, raw[1], 1);
+#pragma unroll
+            for(int i = 0; i < T::A_DMA; ++i)
+                dma_a(a2, 2, i);
+        }
     }
-    wait_vmcnt<2 * T::A_DMA + 2>(); // A(0), B(0) done
+    wait_vmcnt<SPREAD ? T::A_DMA + 3 : 2 * T::A_DMA + 2>(); // A(0), B(0) done
     __builtin_amdgcn_s_barrier();
     {
         convert_piece(wf[0], raw[0], std::integral_constant<int, 0>{});
@@ -202,7 +236,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
     auto tile_body = [&](auto par) __attribute__((always_inline)) {
         constexpr int P = decltype(par)::value, Q = 1 - P;
         const int slot1 = (slot + 1) & 3, slot3 = (slot + 3) & 3;
+        const int slot2 = (slot + 2) & 3;
         const __amdgpu_buffer_rsrc_t b2 = t + 2 < ntiles ? b_rsrc : null_rsrc;
+        const __amdgpu_buffer_rsrc_t a2 = t + 2 < ntiles ? a_rsrc : null_rsrc;
         const __amdgpu_buffer_rsrc_t a3 = t + 3 < ntiles ? a_rsrc : null_rsrc;
 
         auto row_block = [&](auto mt_c) __attribute__((always_inline)) {
@@ -212,36 +248,110 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
             if constexpr(mt == MT - LEAD)
             {
                 // barrier(t): tile t+1 complete for everybody, slot of tile t-1 free
-                wait_vmcnt<T::A_DMA + 4>();
-                __builtin_amdgcn_s_barrier();
+                // (behind the last piece of A(t+1) -- SPREAD: issued in row block 9 of tile t-1 -- came A(t+2) piece 0, B(t+2) x 2
+                // and A(t+2) pieces 1 .. 3)
+                if constexpr(!(PROBE & 4))
+                    wait_vmcnt<SPREAD ? 6 : T::A_DMA + 4>();
+                if constexpr(!(PROBE & 8))
+                    __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
             // fetch the fragment LEAD row blocks ahead (of this tile, or the first ones of the next)
-            if constexpr(mt + LEAD < MT)
-                read_a(slot, mt + LEAD, std::integral_constant<int, wn>{});
-            else
-                read_a(slot1, mt + LEAD - MT, std::integral_constant<int, wn>{});
-            // global loads of later tiles: weights at once (no LDS hazard), activations behind barrier(t)
-            if constexpr(mt == 0)
-                wait_vmcnt<T::A_DMA>(); // B(t+1) has landed (issued a tile ago); behind it: A(t+2) x 4
-            if constexpr(mt == 0)
-                load_b(b2, raw[P], t + 2); // B(t+2): raw[P] held tile t's weights, converted during tile t-1
-            if constexpr(mt >= MT - LEAD)
+            if constexpr(PROBE & 512)
             {
-                dma_a(a3, slot3, mt - (MT - LEAD));
-                if constexpr(mt == MT - 1)
-                    dma_a(a3, slot3, T::A_DMA - 1);
+                if constexpr(mt + LEAD < MT)
+                    read_a_unused(slot, mt + LEAD, std::integral_constant<int, wn>{});
+                else
+                    read_a_unused(slot1, mt + LEAD - MT, std::integral_constant<int, wn>{});
             }
-            acc[0][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], acc[0][mt], 1 /* E5M2 */, 0 /* E4M3 */,
-                                                                           0, scale_w, 0, scale_a);
-            acc[1][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], acc[1][mt], 1, 0, 0, scale_w, 0, scale_a);
+            else if constexpr(!(PROBE & 2))
+            {
+                if constexpr(mt + LEAD < MT)
+                    read_a(slot, mt + LEAD, std::integral_constant<int, wn>{});
+                else
+                    read_a(slot1, mt + LEAD - MT, std::integral_constant<int, wn>{});
+            }
+            // global loads of later tiles: weights at once (no LDS hazard), activations behind barrier(t)
+            if constexpr(!(PROBE & 4))
+            {
+                if constexpr(mt == 0)
+                    wait_vmcnt<T::A_DMA>(); // B(t+1) has landed (issued a tile ago); behind it: A(t+2) x 4
+                if constexpr(mt == 0 && !(PROBE & 2048))
+                    load_b(b2, raw[P], t + 2); // B(t+2): raw[P] held tile t's weights, converted during tile t-1
+                if constexpr(PROBE & 1024)
+                {
+                }
+                else if constexpr(SPREAD)
+                {
+                    // piece 0 of A(t+3) behind barrier(t) (its slot held tile t-1), pieces 1 .. 3 of A(t+2) -- whose slot
+                    // barrier(t-1) freed -- four row blocks apart: eight waves' pieces at a time instead of thirty-two
+                    if constexpr(mt == MT - LEAD)
+                        dma_a(a3, slot3, 0);
+                    if constexpr(mt == 1 || mt == 5 || mt == 9)
+                        dma_a(a2, slot2, 1 + mt / 4);
+                }
+                else if constexpr(mt >= MT - LEAD)
+                {
+                    dma_a(a3, slot3, mt - (MT - LEAD));
+                    if constexpr(mt == MT - 1)
+                        dma_a(a3, slot3, T::A_DMA - 1);
+                }
+            }
+            if constexpr(!(PROBE & 16))
+            {
+                // The plain (unscaled) form of the instruction: zero scale operands select v_mfma_f32_16x16x128_f8f6f4, which
+                // has no scale-load half and issues faster than v_mfma_scale_*; FNUZ activations get their 2^-1 after the loop.
+                // (PROBE & 32: the scaled form with both scales in registers, for comparison)
+                if constexpr(PROBE & 32)
+                {
+                    acc[0][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], acc[0][mt], 1, 0, 0, scale_w, 0, scale_a);
+                    acc[1][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], acc[1][mt], 1, 0, 0, scale_w, 0, scale_a);
+                }
+                else
+                {
+                    acc[0][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], acc[0][mt], 1 /* E5M2 */, 0 /* E4M3 */, 0, 0, 0, 0);
+                    acc[1][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], acc[1][mt], 1, 0, 0, 0, 0, 0);
+                }
+            }
+            else
+            {
+                // (keep the operands alive so that the loads, reads and conversions are not optimised away)
+                asm volatile("" ::"v"(wf[P][0]), "v"(wf[P][1]), "v"(af[w]));
+            }
             // weights of tile t+1: half a piece (4 weights) per row block, its VALU work behind the two MFMAs
-            convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // the two fragment reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            if constexpr(!(PROBE & 1))
+                convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
+            constexpr int ORDER = (PROBE >> 7) & 3; // (diagnostic: other placements of the conversion work)
+            if constexpr(ORDER == 0)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // the two fragment reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            else if constexpr(ORDER == 1)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            else if constexpr(ORDER == 2)
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+            else
+            {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         row_block(std::integral_constant<int, 0>{});
@@ -274,9 +384,27 @@ __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p
             break;
     }
     wait_vmcnt<0>(); // (null-resource loads of tiles past the end still count)
+    if constexpr(PROBE & 512)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(afd[0]), "v"(afd[1]), "v"(afd[2]), "v"(afd[3]));
 
+    // FNUZ bytes were multiplied as the E4M3FN values of the same bits, i.e. twice their value: halve the sums (exact: a
+    // power of two; the products inside the matrix core scale the same way, so the bits equal those of a 2^-1 block scale)
+    if constexpr(!(PROBE & 32))
+        if(p.a_scale != 0x7F7F7F7F)
+        {
+#pragma unroll
+            for(int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for(int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = acc[nt][mt] * 0.5f;
+        }
     __syncthreads(); // every wave is done with the ring before it becomes the C tile image
-    tile256_epilogue<NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
+    if constexpr(PROBE != 0) // (diagnostic builds: one epilogue kind keeps the code small)
+        tile256_epilogue_lds_k<4, false, NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
+    else
+        tile256_epilogue<NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
 }
+
+__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p) { f8s_kernel_body<0>(p); }
 
 } // namespace wq

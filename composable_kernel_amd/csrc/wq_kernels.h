@@ -157,6 +157,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
 // (256 rows x 512 B, row pitch 528 B), then the workgroup streams the tile out row by row with
 // 16-byte stores: each wave-instruction writes two complete 512-byte rows of C, instead of the
 // 16 x 32-byte pieces a direct store of an MFMA accumulator fragment makes.
+#ifndef WQ_EPILOGUE_PHASES
+#define WQ_EPILOGUE_PHASES 4
+#endif
 constexpr int kCTilePitch = 528;
 constexpr int kCTileBytes = 256 * kCTilePitch;
 
@@ -165,9 +168,10 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
                                                        int m0, int n0, int row_w, int col_w, int fr, int fq,
                                                        int wave, int lane)
 {
-    // When every wave's fragments span all 256 rows (1 x 8 wave grid) the tile goes out in two halves: the stores
-    // of rows 0 .. 127 drain while the epilogue arithmetic of rows 128 .. 255 runs.
-    constexpr int PHASES = MT * RSTEP == 256 ? 2 : 1;
+    // When every wave's fragments span all 256 rows (1 x 8 wave grid) the tile goes out in quarters of 64 rows: the stores
+    // of one quarter drain while the epilogue arithmetic of the next runs, so only the first quarter's arithmetic and the
+    // last quarter's stores are exposed (halves left 128 rows of each exposed).
+    constexpr int PHASES = MT * RSTEP == 256 ? WQ_EPILOGUE_PHASES : 1;
     constexpr int MTP    = MT / PHASES;
     uint16_t* cg = (uint16_t*)p.c + (size_t)m0 * p.ldc + n0;
     // D operands in their broadcast forms: one fetch per column block (and per row block for MultiplyMultiply's

@@ -87,9 +87,7 @@ def test_full_d_matrix_indexed_beyond_int32(flag, kb):
     and the split-K reduce) must index it with 64 bits.  Rows above the mark equal a separate launch over those rows
     alone with the D pointer moved to their first row; Add with an integer-valued D is exact, so the comparison is too."""
     M, N, K, ldd, tail = (1 << 18) + 512, 512, 128, 8192, 512
-    if flag == capi.FLAG_GENERIC:
-        M = (1 << 18) + 512          # (the general kernel's grid covers it: 16 rows per block)
-    assert (M - tail) * ldd > (1 << 31)
+    assert (M - tail) * ldd >= (1 << 31)     # (beyond INT_MAX from the first row of the tail on)
     gen = torch.Generator(device="cuda").manual_seed(41)
     q = torch.randint(-8, 8, (N, K), dtype=torch.int8, device="cuda", generator=gen)
     bp = torch.empty((N, K // 2), dtype=torch.uint8, device="cuda")

@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from composable_kernel_amd import capi  # noqa: E402
 
-M = N = K = 4096
+M = N = 4096
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(5)
