@@ -774,6 +774,111 @@ struct DeviceGemmMultiplyMultiply_WeightQuant_gfx950
 };
 
 // ---------------------------------------------------------------------------------------------
+// The same GEMM for int4 weights held ONE PER BYTE -- the reference's int4 convention: ck::int4_t = _BitInt(4) occupies a
+// byte (include/ck/utility/data_type.hpp:10-14), and its int4 examples upload int8 tensors holding -8 .. 7
+// (example/01_gemm/run_gemm_example.inc:93-95,181-191).  BValueType is any one-byte type whose low four bits are the
+// two's-complement value (ck::int4_t, or int8_t at the caller's word that the values lie in -8 .. 7).  Every Run packs the
+// weights two per byte into argument-owned memory (wqgemm_pack_int4, K * N / 2 bytes, untimed -- in the manner of
+// launch_and_time_kernel_with_preprocess, include/ck/host_utility/flush_cache.hpp:107-235) and then runs the operator
+// above on the packed weights, so CK's own callers -- its ckProfiler loop, profile_gemm_multiply_multiply_impl.hpp --
+// reach the fp8 x int4 kernels with tensors generated, uploaded and verified by CK's code unchanged.  Column-major B
+// (K contiguous), K a multiple of 8.
+// ---------------------------------------------------------------------------------------------
+template <typename ALayout, typename BLayout, typename ELayout, typename ADataType, typename BValueType,
+          typename EDataType, typename CDEElementwiseOperation, bool AssumeNoFnuzSpecials = false>
+struct DeviceGemmMultiplyMultiply_Int4Values_gfx950
+    : public DeviceGemmMultipleD<ALayout, BLayout,
+                                 ck::Tuple<tensor_layout::gemm::RowMajor, tensor_layout::gemm::ColumnMajor>, ELayout,
+                                 ADataType, BValueType, ck::Tuple<float, float>, EDataType, element_wise::PassThrough,
+                                 element_wise::PassThrough, CDEElementwiseOperation>
+{
+    static_assert(sizeof(BValueType) == 1, "one int4 value per byte");
+    using Packed      = DeviceGemmMultiplyMultiply_WeightQuant_gfx950<ALayout, BLayout, ELayout, ADataType, ck::wq_int4x2_t,
+                                                                      EDataType, CDEElementwiseOperation, AssumeNoFnuzSpecials>;
+    using PassThrough = element_wise::PassThrough;
+
+    struct Argument : public wq_detail::Argument
+    {
+        const void* b_values = nullptr; // the caller's weights, one per byte
+        index_t ld_values    = 0;
+        std::shared_ptr<void> packed;   // K / 2 bytes per column
+        bool packable        = false;
+    };
+
+    struct Invoker : public BaseInvoker
+    {
+        float Run(const Argument& arg, const StreamConfig& cfg = StreamConfig{})
+        {
+            if(!arg.packable || !arg.packed)
+                throw std::runtime_error("wrong! DeviceGemmMultiplyMultiply_Int4Values_gfx950 has invalid setting: column-major B "
+                                         "with K a multiple of 8 and StrideB >= K, and K * N / 2 bytes of device memory");
+            const wqgemm_problem& p = arg.prob;
+            if(wqgemm_pack_int4((const int8_t*)arg.b_values, arg.ld_values, p.K, p.N, (uint8_t*)arg.packed.get(), p.K / 2,
+                                cfg.stream_id_) != WQ_OK)
+                throw std::runtime_error(std::string("DeviceGemmMultiplyMultiply_Int4Values_gfx950: ") + wqgemm_last_error());
+            return wq_detail::run(p, arg.Workspace(), cfg, "DeviceGemmMultiplyMultiply_Int4Values_gfx950");
+        }
+        float Run(const BaseArgument* p_arg, const StreamConfig& cfg = StreamConfig{}) override
+        {
+            return Run(*dynamic_cast<const Argument*>(p_arg), cfg);
+        }
+    };
+
+    static Argument MakeArgument(const void* p_a, const void* p_b, std::array<const void*, 2> p_ds, void* p_e, index_t M,
+                                 index_t N, index_t K, index_t StrideA, index_t StrideB, std::array<index_t, 2> StrideDs,
+                                 index_t StrideE, PassThrough, PassThrough, CDEElementwiseOperation cde)
+    {
+        Argument arg;
+        arg.b_values  = p_b;
+        arg.ld_values = StrideB;
+        arg.packable  = std::is_same_v<BLayout, tensor_layout::gemm::ColumnMajor> && K > 0 && N > 0 && K % 8 == 0 && StrideB >= K;
+        if(arg.packable)
+        {
+            void* ptr = nullptr;
+            if(hipMalloc(&ptr, (size_t)N * (K / 2)) == hipSuccess)
+                arg.packed = std::shared_ptr<void>(ptr, [](void* q) { (void)hipFree(q); });
+            else
+                (void)hipGetLastError();
+        }
+        // the packed problem: same operands, B = the packed copy with K / 2 bytes per column
+        wq_detail::Argument inner = Packed::MakeArgument(p_a, arg.packed.get(), p_ds, p_e, M, N, K, StrideA, K, StrideDs, StrideE,
+                                                         PassThrough{}, PassThrough{}, cde);
+        arg.prob            = inner.prob;
+        arg.owned_workspace = inner.owned_workspace;
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{}; }
+    static bool IsSupportedArgument(const Argument& arg)
+    {
+        return arg.packable && arg.packed && wq_detail::supported(arg.prob);
+    }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument> MakeArgumentPointer(const void* p_a, const void* p_b, std::array<const void*, 2> p_ds,
+                                                      void* p_e, index_t M, index_t N, index_t K, index_t StrideA,
+                                                      index_t StrideB, std::array<index_t, 2> StrideDs, index_t StrideE,
+                                                      PassThrough a_op, PassThrough b_op,
+                                                      CDEElementwiseOperation cde_op) override
+    {
+        return std::make_unique<Argument>(
+            MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE, a_op, b_op, cde_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(); }
+    size_t GetWorkSpaceSize(const BaseArgument* p_arg) const override
+    {
+        return wqgemm_workspace_bytes(&dynamic_cast<const Argument*>(p_arg)->prob);
+    }
+    std::string GetTypeString() const override
+    {
+        return std::string("DeviceGemmMultiplyMultiply_Int4Values_gfx950<") +
+               (std::is_same_v<ADataType, ck::wq_f8_e4m3fn_t> ? "F8_E4M3FN" : AssumeNoFnuzSpecials ? "F8_FNUZ_NoSpecials" : "F8_FNUZ") +
+               ", int4 per byte -> I4x2 packed per Run>";
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Split-K over weight-quantized B:  C = c_op( sum over KBatch slices of A[M,K] * cvt_A(B[K,N]) [, D0] )
 // A fp16 / bf16, B int8 (or offset uint8 / packed int4) with no weight scale -- ReferenceGemm's arithmetic with
 // BDataType = int8 (library/include/ck/library/reference_tensor_operation/cpu/reference_gemm.hpp:60-108), the problem of

@@ -123,6 +123,26 @@ def test_reference_profiler_splitk_loop_dropin(dtype, layout, kbatch):
         assert r.stdout.count("Perf:") >= 10
 
 
+@pytest.mark.parametrize("dtype,init,extra", [(8, 1, ()), (9, 2, ()), (10, 1, ()), (10, 2, ()), (11, 2, ()),
+                                              (10, 2, (2, 7, 64)), (8, 2, (1, 5, 64))])
+def test_reference_profiler_multiply_multiply_loop_dropin(dtype, init, extra):
+    """CK's OWN ckProfiler MultiplyMultiply loop (profile_gemm_multiply_multiply_impl.hpp, unmodified) instantiated for fp8
+    activations x ck::int4_t weights (one value per byte, CK's int4 convention): CK generates and uploads the tensors --
+    D0 and D1 as full (M, N) matrices, row- and column-major -- runs ReferenceGemm + MultiplyMultiply on the host and
+    check_err; the gfx950 operator is found through the factory header this engine adds, packs the weights two per byte
+    and runs the fp8 matrix-core kernel (E4M3FN bytes, data types 10 / 11) or the exact fp16-image route (FNUZ bytes,
+    8 / 9).  `extra` = warm-up, iterations, rotating-buffer MB: the flush-cache StreamConfig of the loop's timed run."""
+    M, N, K = 512, 768, 1024
+    r = _run(os.path.join(EX, "_ref_build", "ck_profile_gemm_multiply_multiply_weight_quant_dropin"),
+             "gemm_multiply_multiply", dtype, 1, 1, init, 0, 1, M, N, K, -1, -1, -1, -1, -1, *extra)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "found 1 instances" in r.stdout and "Best Perf" in r.stdout and "does not support" not in r.stdout
+    assert "DeviceGemmMultiplyMultiply_Int4Values_gfx950<" + ("F8_E4M3FN" if dtype >= 10 else "F8_FNUZ") in r.stdout
+    if extra:
+        # 64 MB over A (0.5 MiB) + B (0.75 MiB, one byte per weight) + D0, D1 (1.5 MiB each): more copies than iterations
+        assert f"rotating count: {extra[1]}" in r.stdout
+
+
 @pytest.mark.parametrize("fmt,gelu,init", [(0, 0, 1), (1, 0, 1), (1, 1, 2), (2, 0, 1), (2, 1, 2)])
 def test_fp8_int4_multiply_multiply_example(fmt, gelu, init):
     """example/65's flow (fp8 A, D0 per column, D1 per row, host ReferenceGemm + check_err): FNUZ bytes through
