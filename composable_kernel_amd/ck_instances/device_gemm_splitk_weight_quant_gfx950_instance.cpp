@@ -21,20 +21,24 @@ using Row         = ck::tensor_layout::gemm::RowMajor;
 using Col         = ck::tensor_layout::gemm::ColumnMajor;
 using PassThrough = ck::tensor_operation::element_wise::PassThrough;
 
-template <typename BLayout, typename T>
+template <typename ALayout, typename BLayout, typename T>
 using SplitKPtrs =
-    std::vector<std::unique_ptr<DeviceGemmSplitK<Row, BLayout, Row, T, int8_t, T, PassThrough, PassThrough, PassThrough>>>;
+    std::vector<std::unique_ptr<DeviceGemmSplitK<ALayout, BLayout, Row, T, int8_t, T, PassThrough, PassThrough, PassThrough>>>;
 
-template <typename BLayout, typename T>
-static void add(SplitKPtrs<BLayout, T>& instances)
+template <typename ALayout, typename BLayout, typename T>
+static void add(SplitKPtrs<ALayout, BLayout, T>& instances)
 {
-    instances.push_back(std::make_unique<DeviceGemmSplitK_WeightQuant_gfx950<Row, BLayout, Row, T, int8_t, T, PassThrough>>());
+    instances.push_back(std::make_unique<DeviceGemmSplitK_WeightQuant_gfx950<ALayout, BLayout, Row, T, int8_t, T, PassThrough>>());
 }
 
-void add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_mk_kn_mn_instances(SplitKPtrs<Row, ck::bhalf_t>& i) { add<Row, ck::bhalf_t>(i); }
-void add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_mk_nk_mn_instances(SplitKPtrs<Col, ck::bhalf_t>& i) { add<Col, ck::bhalf_t>(i); }
-void add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_kn_mn_instances(SplitKPtrs<Row, ck::half_t>& i) { add<Row, ck::half_t>(i); }
-void add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_nk_mn_instances(SplitKPtrs<Col, ck::half_t>& i) { add<Col, ck::half_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_mk_kn_mn_instances(SplitKPtrs<Row, Row, ck::bhalf_t>& i) { add<Row, Row, ck::bhalf_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_mk_nk_mn_instances(SplitKPtrs<Row, Col, ck::bhalf_t>& i) { add<Row, Col, ck::bhalf_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_kn_mn_instances(SplitKPtrs<Row, Row, ck::half_t>& i) { add<Row, Row, ck::half_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_nk_mn_instances(SplitKPtrs<Row, Col, ck::half_t>& i) { add<Row, Col, ck::half_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_km_kn_mn_instances(SplitKPtrs<Col, Row, ck::bhalf_t>& i) { add<Col, Row, ck::bhalf_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_km_nk_mn_instances(SplitKPtrs<Col, Col, ck::bhalf_t>& i) { add<Col, Col, ck::bhalf_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_km_kn_mn_instances(SplitKPtrs<Col, Row, ck::half_t>& i) { add<Col, Row, ck::half_t>(i); }
+void add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_km_nk_mn_instances(SplitKPtrs<Col, Col, ck::half_t>& i) { add<Col, Col, ck::half_t>(i); }
 
 } // namespace instance
 } // namespace device

@@ -33,6 +33,12 @@ WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_mk_kn_mn_
 WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_mk_nk_mn_instances, Row, Col, BF16)
 WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_kn_mn_instances, Row, Row, F16)
 WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_nk_mn_instances, Row, Col, F16)
+// column-major activations (the km_* layouts of library/include/ck/library/tensor_operation_instance/gpu/gemm_splitk.hpp):
+// the general kernel runs them
+WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_km_kn_mn_instances, Col, Row, BF16)
+WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_km_nk_mn_instances, Col, Col, BF16)
+WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_km_kn_mn_instances, Col, Row, F16)
+WQ_SPLITK_DECL(add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_km_nk_mn_instances, Col, Col, F16)
 #undef WQ_SPLITK_DECL
 
 template <typename ADataType, typename ALayout, typename BLayout, typename CLayout, typename ComputeType>
@@ -61,6 +67,17 @@ struct DeviceOperationInstanceFactory<
                 add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_kn_mn_instances(op_ptrs);
             else if constexpr(is_same_v<ADataType, half_t> && is_same_v<BLayout, Col>)
                 add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_mk_nk_mn_instances(op_ptrs);
+        }
+        else if constexpr(is_same_v<ComputeType, ADataType> && is_same_v<ALayout, Col> && is_same_v<CLayout, Row>)
+        {
+            if constexpr(is_same_v<ADataType, bhalf_t> && is_same_v<BLayout, Row>)
+                add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_km_kn_mn_instances(op_ptrs);
+            else if constexpr(is_same_v<ADataType, bhalf_t> && is_same_v<BLayout, Col>)
+                add_device_gemm_splitk_weight_quant_gfx950_bf16_i8_bf16_km_nk_mn_instances(op_ptrs);
+            else if constexpr(is_same_v<ADataType, half_t> && is_same_v<BLayout, Row>)
+                add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_km_kn_mn_instances(op_ptrs);
+            else if constexpr(is_same_v<ADataType, half_t> && is_same_v<BLayout, Col>)
+                add_device_gemm_splitk_weight_quant_gfx950_f16_i8_f16_km_nk_mn_instances(op_ptrs);
         }
         return op_ptrs;
     }

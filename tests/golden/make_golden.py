@@ -294,13 +294,33 @@ def gemm_cases(ref) -> dict:
     return out
 
 
+def splitk_shapes(ref) -> dict:
+    """The K extents of the reference's own split-K test that are not whole 64-k tiles (test/gemm_split_k/
+    test_gemm_splitk_ut_cases.inc:3-217: K = 320 at N = 512; PaddK K = 437) on example/35's arithmetic:
+    ReferenceGemm<bhalf, int8, bhalf, float> over the whole K, B row-major (K, N).  A seed of their own: the file is
+    independent of gemm_cases.npz."""
+    rng = np.random.default_rng(20250437)
+    out = {}
+    for tag, (M, N, K) in {"k320": (6, 512, 320), "k437": (127, 512, 437)}.items():
+        brow = rng.integers(-2, 2, (K, N)).astype(np.int8)
+        brow_full = rng.integers(-128, 128, (K, N)).astype(np.int8)
+        a_int = bf16_bits_trunc(rng.integers(-2, 2, (M, K)).astype(np.float32))
+        a_dec = bf16_bits_trunc(rng.uniform(-0.5, 0.5, (M, K)))
+        out[f"{tag}_shape"] = np.array([M, N, K], np.int32)
+        out[f"{tag}_a_int"], out[f"{tag}_a_dec"], out[f"{tag}_brow"], out[f"{tag}_brow_full"] = a_int, a_dec, brow, brow_full
+        out[f"{tag}_c_int"] = ref.gemm_bf16_i8_unscaled(a_int, brow, M, N, K, K, N, 1, N)
+        out[f"{tag}_c_dec"] = ref.gemm_bf16_i8_unscaled(a_dec, brow_full, M, N, K, K, N, 1, N)
+    return out
+
+
 def main() -> None:
     ref = binding.load_ref()
     if ref is None:
         raise SystemExit("reference tree not mounted: cannot regenerate golden vectors")
     np.savez_compressed(os.path.join(OUT, "scalars.npz"), **scalars(ref))
     np.savez_compressed(os.path.join(OUT, "gemm_cases.npz"), **gemm_cases(ref))
-    for f in ("scalars.npz", "gemm_cases.npz"):
+    np.savez_compressed(os.path.join(OUT, "splitk_shapes.npz"), **splitk_shapes(ref))
+    for f in ("scalars.npz", "gemm_cases.npz", "splitk_shapes.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
 
 

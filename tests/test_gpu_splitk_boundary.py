@@ -193,3 +193,42 @@ def test_splitk_multi_step_c_abi(port):
         capi.splitk_multi_step(bad, None, 0, 2, ws2.data_ptr(), st)
     with pytest.raises(capi.WqError):
         capi.splitk_multi_step(p2, None, 0, 3, ws2.data_ptr(), st)
+
+
+@pytest.mark.parametrize("tag", ["k320", "k437"])
+@pytest.mark.parametrize("kb", [1, 2, 3, 5, 8])
+def test_reference_splitk_shapes_golden(tag, kb):
+    """The K extents of the reference's split-K test that are not whole 64-k tiles per slice (K = 320: five tiles; PaddK
+    K = 437: not a multiple of anything), KBatch from its list, against outputs of the reference's own ReferenceGemm:
+    bit-exact on the integer set, within one bf16 step on the decimal set.  Whatever kernel the planner picks."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "splitk_shapes.npz"))
+    M, N, K = (int(v) for v in g[f"{tag}_shape"])
+    got = run_fpaintb(g[f"{tag}_a_int"], g[f"{tag}_brow"], None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
+                      b_layout=capi.ROW_MAJOR, ldb=N, k_batch=kb)
+    np.testing.assert_array_equal(got, g[f"{tag}_c_int"].reshape(M, N))
+    got = run_fpaintb(g[f"{tag}_a_dec"], g[f"{tag}_brow_full"], None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8,
+                      b_layout=capi.ROW_MAJOR, ldb=N, k_batch=kb)
+    exp = g[f"{tag}_c_dec"].reshape(M, N)
+    ulp = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+    tiny = np.abs(bits_to_f32(got, capi.BF16) - bits_to_f32(exp, capi.BF16)) <= 1e-3
+    assert (ulp[~tiny] <= 1).all(), ulp[~tiny].max()
+    # the same weights K-contiguous
+    q = np.ascontiguousarray(g[f"{tag}_brow"].T)
+    got = run_fpaintb(g[f"{tag}_a_int"], q, None, M, N, K, a_dtype=capi.BF16, b_dtype=capi.I8, k_batch=kb)
+    np.testing.assert_array_equal(got, g[f"{tag}_c_int"].reshape(M, N))
+
+
+def test_reference_splitk_test_shapes_through_ck_profiling_loop():
+    """examples/_ref_build/ck_test_gemm_splitk_weight_quant_dropin: every shape of CK's split-K test x KBatch {1, 2, 3, 5, 8} x
+    four layouts x two activation types through CK's unmodified profile_gemm_splitk_impl.hpp over the gfx950 registration:
+    no wrong answer, and (as the build stands) no refusal either."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "_ref_build",
+                       "ck_test_gemm_splitk_weight_quant_dropin")
+    assert os.path.exists(exe), "examples/_ref_build/ck_test_gemm_splitk_weight_quant_dropin is not built (make -C examples dropin)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ", 0 wrong" in r.stdout and "WRONG" not in r.stdout
+    assert " 0 refused" in r.stdout

@@ -1,7 +1,10 @@
 """The plain-C checker (oracle/wq_oracle.c) against golden vectors produced by the reference's
 own host code (tests/golden/make_golden.py).  Bit-exact everywhere: these are integer / bit-level
 results or fp32 loops with a fixed evaluation order."""
+import os
+
 import numpy as np
+import pytest
 
 
 def _bits(x):
@@ -324,3 +327,15 @@ def test_grouped_scale_cases_bf16(port, golden_gemm):
     M, N, K = 48, 64, 128
     e = port.gemm_bf16_i8_grouped(g["bf16_a"], g["bf16_bcol"], g["bf16_s"][None, :], M, N, K, K, 1, K, N, 0, K, N)
     np.testing.assert_array_equal(e, g["bf16_e_col_ep0"])
+
+
+@pytest.mark.parametrize("tag", ["k320", "k437"])
+def test_splitk_reference_shapes_golden(port, tag):
+    """K = 320 and K = 437 of the reference's split-K test (test/gemm_split_k/test_gemm_splitk_ut_cases.inc): the plain-C
+    checker reproduces the reference's ReferenceGemm<bhalf, int8, bhalf, float> outputs bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "splitk_shapes.npz"))
+    M, N, K = (int(v) for v in g[f"{tag}_shape"])
+    for kind, b in (("int", g[f"{tag}_brow"]), ("dec", g[f"{tag}_brow_full"])):
+        q = np.ascontiguousarray(b.T)      # (N, K): K contiguous per column
+        got = port.gemm_bf16_i8(g[f"{tag}_a_{kind}"], q, None, M, N, K, K, 1, K, N, 0)
+        np.testing.assert_array_equal(got, g[f"{tag}_c_{kind}"])
