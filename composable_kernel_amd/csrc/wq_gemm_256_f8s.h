@@ -50,12 +50,17 @@ struct Mfma256F8S
 //   128, 256, 384: other instruction orders inside a row block
 //   512 fragment reads issued but never consumed (the MFMAs keep the fragments of the prologue)
 //   1024 no LDS-DMA in the loop (weight loads stay)   2048 no weight loads in the loop (LDS-DMA stays)
+//   8192 epilogue without global stores   16384 epilogue without arithmetic (conversion and stores only)
+//   4096 cycle stamps (s_memtime) at entry, first row block, end of the K loop and exit -> p.dbg[workgroup][wave][4]
 template <int PROBE>
 __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 {
     using T = Mfma256F8S;
     constexpr int MT = 16, NT = 2, LEAD = T::LEAD, WIN = LEAD + 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    [[maybe_unused]] long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+    if constexpr(PROBE & 4096)
+        stamp0 = __builtin_amdgcn_s_memtime();
 
     const int lane  = threadIdx.x & 63;
     const int wave  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -120,11 +125,13 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
     };
 
     f4_t acc[NT][MT];
+    auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for(int nt = 0; nt < NT; ++nt)
+        for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for(int mt = 0; mt < MT; ++mt)
-            acc[nt][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
+            for(int mt = 0; mt < MT; ++mt)
+                acc[nt][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
+    };
 
     // this lane's two 16-byte chunks of row fr of row block 0 (swizzled position inside the 128-byte row)
     int a_off[2];
@@ -177,6 +184,7 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 
     if(ntiles <= 0)
     {
+        clear_acc();
         tile256_epilogue<NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
         return;
     }
@@ -210,6 +218,9 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                 dma_a(a2, 2, i);
         }
     }
+    // (everything the first loads do not need happens while they are in flight: the 128 accumulator registers are cleared here)
+    __builtin_amdgcn_sched_barrier(0);
+    clear_acc();
     wait_vmcnt<SPREAD ? T::A_DMA + 3 : 2 * T::A_DMA + 2>(); // A(0), B(0) done
     __builtin_amdgcn_s_barrier();
     {
@@ -227,6 +238,8 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
     read_a(0, 2, std::integral_constant<int, 2>{});
     static_assert(LEAD == 3, "prologue fetches LEAD fragments");
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr(PROBE & 4096)
+        stamp1 = __builtin_amdgcn_s_memtime();
 
     // ---- one K tile; PAR = t & 1 selects the register sets at compile time.  Straight-line: loads of tiles past the
     // last one are issued through the null resource, the reads and the conversion for a tile that does not exist
@@ -384,6 +397,8 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
             break;
     }
     wait_vmcnt<0>(); // (null-resource loads of tiles past the end still count)
+    if constexpr(PROBE & 4096)
+        stamp2 = __builtin_amdgcn_s_memtime();
     if constexpr(PROBE & 512)
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(afd[0]), "v"(afd[1]), "v"(afd[2]), "v"(afd[3]));
 
@@ -399,10 +414,24 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                     acc[nt][mt] = acc[nt][mt] * 0.5f;
         }
     __syncthreads(); // every wave is done with the ring before it becomes the C tile image
-    if constexpr(PROBE != 0) // (diagnostic builds: one epilogue kind keeps the code small)
+    if constexpr((PROBE & 8192) != 0) // (diagnostic: the epilogue without its global stores)
+        tile256_epilogue_lds_k<4, false, NT, MT, 16, 16, true>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
+    else if constexpr((PROBE & 16384) != 0) // (diagnostic: conversion and stores only)
+        tile256_epilogue_lds_k<0, false, NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
+    else if constexpr(PROBE != 0) // (diagnostic builds: one epilogue kind keeps the code small)
         tile256_epilogue_lds_k<4, false, NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
     else
         tile256_epilogue<NT, MT>(p, acc, lds, m0, n0, 0, col_w, fr, fq, wave, lane);
+    if constexpr(PROBE & 4096)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores of C have been acknowledged
+        const long long stamp3 = __builtin_amdgcn_s_memtime();
+        if(lane == 0 && p.dbg)
+        {
+            long long* out = (long long*)p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+            out[0] = stamp1 - stamp0, out[1] = stamp2 - stamp1, out[2] = stamp3 - stamp2, out[3] = stamp0;
+        }
+    }
 }
 
 __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p) { f8s_kernel_body<0>(p); }

@@ -163,7 +163,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, const f4_t (&
 constexpr int kCTilePitch = 528;
 constexpr int kCTileBytes = 256 * kCTilePitch;
 
-template <int KIND, bool BF16, int NT, int MT, int RSTEP = 16, int CSTEP = 16>
+template <int KIND, bool BF16, int NT, int MT, int RSTEP = 16, int CSTEP = 16, bool NO_STORE = false /* timing diagnostics only */>
 __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, const f4_t (&acc)[NT][MT], uint8_t* lds,
                                                        int m0, int n0, int row_w, int col_w, int fr, int fq,
                                                        int wave, int lane)
@@ -187,15 +187,20 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
             d0c[nt] = load_d0_cols4<KIND>(p.epi, n), d1c[nt] = load_d1_cols4<KIND>(p.epi, n);
         }
     }
+    // (the per-row operand of every row block in one batch, ahead of the first phase: one memory latency instead of one
+    // per phase)
+    float d1r[MT];
+    if(bcast)
+    {
+#pragma unroll
+        for(int mt = 0; mt < MT; ++mt)
+            d1r[mt] = load_d1_row<KIND>(p.epi, min(m0 + row_w + mt * RSTEP + fr, p.M - 1));
+    }
 #pragma unroll
     for(int ph = 0; ph < PHASES; ++ph)
     {
         if(bcast)
         {
-            float d1r[MTP];
-#pragma unroll
-            for(int mi = 0; mi < MTP; ++mi)
-                d1r[mi] = load_d1_row<KIND>(p.epi, min(m0 + row_w + (ph * MTP + mi) * RSTEP + fr, p.M - 1));
 #pragma unroll
             for(int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -203,7 +208,7 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
                 {
                     const int mt = ph * MTP + mi;
                     const int r = row_w + mt * RSTEP + fr, c = col_w + nt * CSTEP + fq * 4;
-                    const u2_t pk = pack_out4<BF16>(apply_epilogue4_bcast<KIND>(acc[nt][mt], d0c[nt], d1c[nt], d1r[mi]));
+                    const u2_t pk = pack_out4<BF16>(apply_epilogue4_bcast<KIND>(acc[nt][mt], d0c[nt], d1c[nt], d1r[mt]));
                     *(u2_t*)(lds + r * kCTilePitch + c * 2) = pk;
                 }
         }
@@ -230,7 +235,9 @@ __device__ __forceinline__ void tile256_epilogue_lds_k(const GemmParams& p, cons
             const int r   = ph * ROWS_PH + wave * (ROWS_PH / 8) + 2 * i + (lane >> 5);
             const int c16 = lane & 31;
             const u4_t v  = *(const u4_t*)(lds + r * kCTilePitch + c16 * 16);
-            if(m0 + r < p.M) // the last row tile may be partial
+            if constexpr(NO_STORE)
+                asm volatile("" ::"v"(v));
+            else if(m0 + r < p.M) // the last row tile may be partial
                 *(u4_t*)(cg + (size_t)r * p.ldc + c16 * 8) = v;
         }
     }

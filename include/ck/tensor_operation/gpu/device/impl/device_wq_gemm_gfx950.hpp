@@ -39,9 +39,11 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "ck/ck.hpp"
 #include "ck/utility/data_type.hpp"
@@ -214,6 +216,107 @@ inline std::string type_string(const wqgemm_problem& prob)
     return buf;
 }
 
+// Device memory for the arguments' own scratch, recycled: an Argument takes a block when it is made and hands it back when
+// its last copy goes, so a caller that makes arguments in a loop (the profilers do, once per instance and problem) meets
+// hipMalloc -- a call that synchronises the device -- only until the pool holds a block that fits.  Every Argument still
+// has a block of its own while it lives (arguments used at the same time on different streams never share scratch).
+// Blocks are kept per device, at most kMaxIdle of them and kMaxIdleBytes in all; what exceeds that is freed at once.  The
+// pool itself is never destroyed (at process exit the HIP runtime may be gone before static destructors run).
+class ScratchPool
+{
+    public:
+    static ScratchPool& instance()
+    {
+        static ScratchPool* pool = new ScratchPool;
+        return *pool;
+    }
+    std::shared_ptr<void> take(size_t bytes)
+    {
+        int dev = 0;
+        if(hipGetDevice(&dev) != hipSuccess)
+            return nullptr;
+        Block blk{nullptr, 0, dev, nullptr};
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            // the smallest idle block of this device that fits and is not more than twice as large
+            int best = -1;
+            for(int i = 0; i < (int)idle_.size(); ++i)
+                if(idle_[i].dev == dev && idle_[i].bytes >= bytes && idle_[i].bytes <= 2 * bytes + (1u << 20) &&
+                   (best < 0 || idle_[i].bytes < idle_[best].bytes))
+                    best = i;
+            if(best >= 0)
+            {
+                blk = idle_[best];
+                idle_bytes_ -= blk.bytes;
+                idle_.erase(idle_.begin() + best);
+            }
+        }
+        if(blk.ptr && blk.idle_since)
+        {
+            // launches that used the block were enqueued before it came back: wait for them (normally long done)
+            (void)hipEventSynchronize(blk.idle_since);
+            (void)hipEventDestroy(blk.idle_since);
+            blk.idle_since = nullptr;
+        }
+        if(!blk.ptr)
+        {
+            if(hipMalloc(&blk.ptr, bytes) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            blk.bytes = bytes;
+        }
+        return std::shared_ptr<void>(blk.ptr, [blk](void*) { ScratchPool::instance().give(blk); });
+    }
+
+    private:
+    struct Block
+    {
+        void* ptr;
+        size_t bytes;
+        int dev;
+        hipEvent_t idle_since; // recorded on the default stream when the block came back (orders after work on blocking streams)
+    };
+    static constexpr size_t kMaxIdle = 8, kMaxIdleBytes = size_t(2) << 30;
+    void give(Block blk)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            if(idle_.size() < kMaxIdle && idle_bytes_ + blk.bytes <= kMaxIdleBytes)
+            {
+                int cur = 0;
+                if(hipGetDevice(&cur) == hipSuccess && cur == blk.dev && hipEventCreateWithFlags(&blk.idle_since, hipEventDisableTiming) == hipSuccess)
+                {
+                    if(hipEventRecord(blk.idle_since, nullptr) != hipSuccess)
+                    {
+                        (void)hipEventDestroy(blk.idle_since);
+                        blk.idle_since = nullptr;
+                        (void)hipDeviceSynchronize();
+                    }
+                }
+                else
+                {
+                    blk.idle_since = nullptr;
+                    (void)hipGetLastError();
+                }
+                idle_.push_back(blk);
+                idle_bytes_ += blk.bytes;
+                return;
+            }
+        }
+        // (the block may still be in use by launches in flight: hipFree waits for the device)
+        int cur = 0;
+        const bool swap = hipGetDevice(&cur) == hipSuccess && cur != blk.dev && hipSetDevice(blk.dev) == hipSuccess;
+        (void)hipFree(blk.ptr);
+        if(swap)
+            (void)hipSetDevice(cur);
+    }
+    std::mutex mu_;
+    std::vector<Block> idle_;
+    size_t idle_bytes_ = 0;
+};
+
 // Argument / Invoker shared by every operator below.
 struct Argument : public BaseArgument
 {
@@ -232,17 +335,12 @@ struct Argument : public BaseArgument
         const size_t bytes = wqgemm_workspace_bytes(&prob);
         if(bytes == 0)
             return;
-        void* ptr           = nullptr;
-        const hipError_t rc = hipMalloc(&ptr, bytes);
-        if(rc == hipSuccess)
-            owned_workspace = std::shared_ptr<void>(ptr, [](void* q) { (void)hipFree(q); });
-        else
+        owned_workspace = ScratchPool::instance().take(bytes);
+        if(!owned_workspace)
         {
-            (void)hipGetLastError();
             static bool told = false;
             if(!told)
-                std::cerr << "wqgemm: could not allocate " << bytes << " bytes of operator-owned scratch ("
-                          << hipGetErrorString(rc) << "): "
+                std::cerr << "wqgemm: could not allocate " << bytes << " bytes of operator-owned scratch: "
                           << (prob.k_batch > 1 ? "split-K cannot run" : "the general kernel will run, far slower")
                           << "; hand a workspace over with SetWorkSpacePointer" << std::endl;
             told = true;
@@ -834,11 +932,7 @@ struct DeviceGemmMultiplyMultiply_Int4Values_gfx950
         arg.packable  = std::is_same_v<BLayout, tensor_layout::gemm::ColumnMajor> && K > 0 && N > 0 && K % 8 == 0 && StrideB >= K;
         if(arg.packable)
         {
-            void* ptr = nullptr;
-            if(hipMalloc(&ptr, (size_t)N * (K / 2)) == hipSuccess)
-                arg.packed = std::shared_ptr<void>(ptr, [](void* q) { (void)hipFree(q); });
-            else
-                (void)hipGetLastError();
+            arg.packed = wq_detail::ScratchPool::instance().take((size_t)N * (K / 2));
         }
         // the packed problem: same operands, B = the packed copy with K / 2 bytes per column
         wq_detail::Argument inner = Packed::MakeArgument(p_a, arg.packed.get(), p_ds, p_e, M, N, K, StrideA, K, StrideDs, StrideE,

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -58,7 +59,7 @@ int main(int argc, char** argv)
     for(int i = 1; i < argc; ++i)
         ks.push_back(atoi(argv[i]));
     if(ks.empty())
-        ks = {4096, 16384};
+        ks = {128, 4096};
     const int M = 4096, N = 4096;
     for(int K : ks)
     {
@@ -103,10 +104,24 @@ int main(int argc, char** argv)
         struct R { const char* name; float us; };
         std::vector<R> r;
         r.push_back({"full kernel", time_probe<0>(gp, grid, iters)});
-        r.push_back({"fragment reads issued, never consumed", time_probe<512>(gp, grid, iters)});
-        r.push_back({"no LDS-DMA in the loop (weights loaded)", time_probe<1024 + 8>(gp, grid, iters)});
-        r.push_back({"no weight loads in the loop (LDS-DMA stays)", time_probe<2048>(gp, grid, iters)});
-        r.push_back({"full kernel again", time_probe<0>(gp, grid, iters)});
+        auto stamped = [&](auto probe, const char* name) {
+            constexpr int P = decltype(probe)::value;
+            long long* dbg;
+            CHECK(hipMalloc(&dbg, 256 * 8 * 4 * 8));
+            gp.dbg = dbg;
+            const float us = time_probe<P>(gp, grid, iters);
+            r.push_back({name, us});
+            std::vector<long long> h(256 * 8 * 4);
+            CHECK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            double s0 = 0, s1 = 0, s2 = 0;
+            for(int i = 0; i < 256 * 8; ++i)
+                s0 += h[i * 4], s1 += h[i * 4 + 1], s2 += h[i * 4 + 2];
+            printf("K = %d %s: stamps (shader cycles, mean over 2048 waves): prologue %.0f, K loop %.0f (%.0f per tile), epilogue + store %.0f; "
+                   "kernel %.2f us\n", K, name, s0 / 2048, s1 / 2048, s1 / 2048 / ntiles, s2 / 2048, us);
+            gp.dbg = nullptr;
+            CHECK(hipFree(dbg));
+        };
+        stamped(std::integral_constant<int, 4096>{}, "stamped build");
         printf("K = %d (%d K tiles of 128; ideal matrix-pipe time per tile at 2.4 GHz: 0.853 us)\n", K, ntiles);
         for(auto& x : r)
             printf("  %-58s %8.2f us   %7.1f TFLOP/s\n", x.name, x.us, 2.0 * M * N * K / x.us / 1e6);
