@@ -58,6 +58,9 @@ class Problem(C.Structure):
         ("k_batch", C.c_int32), ("k_begin", C.c_int32), ("k_end", C.c_int32), ("flags", C.c_int32),
         ("ldd0", C.c_int32), ("ldd1", C.c_int32),
         ("scale_group_k", C.c_int32), ("ld_scale", C.c_int32),
+        ("a_block_scale", C.c_void_p), ("b_block_scale", C.c_void_p),
+        ("scale_block_m", C.c_int32), ("scale_block_n", C.c_int32), ("scale_block_k", C.c_int32),
+        ("ld_a_scale", C.c_int32), ("ld_b_scale", C.c_int32),
     ]
 
 
@@ -244,7 +247,8 @@ def splitk_kread(K: int, k_batch: int, granule: int = 64) -> int:
 def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, lda=None, ldb=None,
                     ldc=None, epilogue=EPI_PASSTHROUGH, d0=None, d1=None, k_batch=1, k_begin=0,
                     k_end=0, c_dtype=None, b_layout=COL_MAJOR, a_layout=ROW_MAJOR, requant=0.0, flags=0,
-                    ldd0=0, ldd1=0, scale_group_k=0, ld_scale=0) -> Problem:
+                    ldd0=0, ldd1=0, scale_group_k=0, ld_scale=0, a_block_scale=None, b_block_scale=None,
+                    scale_block=(128, 128, 128), ld_a_scale=0, ld_b_scale=0) -> Problem:
     """Fill a Problem from raw device pointers (ints).  Strides default to packed tensors."""
     p = Problem()
     p.a_dtype, p.b_dtype, p.scale_dtype = a_dtype, b_dtype, a_dtype
@@ -260,4 +264,8 @@ def fpAintB_problem(a, b, scale, c, M, N, K, *, a_dtype=F16, b_dtype=I4_PACKED, 
     p.k_batch, p.k_begin, p.k_end, p.flags = k_batch, k_begin, k_end, flags
     p.ldd0, p.ldd1 = ldd0, ldd1
     p.scale_group_k, p.ld_scale = scale_group_k, ld_scale
+    p.a_block_scale, p.b_block_scale = a_block_scale, b_block_scale
+    if a_block_scale is not None or b_block_scale is not None:
+        p.scale_block_m, p.scale_block_n, p.scale_block_k = scale_block
+        p.ld_a_scale, p.ld_b_scale = ld_a_scale, ld_b_scale
     return p

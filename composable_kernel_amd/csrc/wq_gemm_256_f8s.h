@@ -40,6 +40,13 @@ struct Mfma256F8S
     static constexpr int LDS_BYTES   = RING_BYTES > kCTileBytes ? RING_BYTES : kCTileBytes;
     static constexpr int A_DMA       = A_TILE / 1024 / 8; // LDS-DMA instructions per wave per tile: 4
     static constexpr int LEAD        = 3;                 // row blocks between a fragment's fetch and its MFMAs (window of 4 divides 16)
+    // block-scale tables (ABSCALE kernel): [K tile][2] for the two row halves, then [wave][K tile], one spare tile each
+    static constexpr int MAX_TILES_ABSCALE = 640;
+    static constexpr int TAB_LD            = MAX_TILES_ABSCALE + 1;
+    static constexpr int TAB_A             = kCTileBytes > RING_BYTES ? kCTileBytes : RING_BYTES;
+    static constexpr int TAB_B             = TAB_A + 2 * TAB_LD * 4;
+    static constexpr int LDS_BYTES_ABSCALE = TAB_B + 8 * TAB_LD * 4;
+    static_assert(LDS_BYTES_ABSCALE <= 160 * 1024, "the scale tables must fit behind the C tile image");
 };
 
 // PROBE = 0 is the product kernel.  Other values exist only for the timing diagnostics in tools/f8_probe.hip: each bit
@@ -52,7 +59,11 @@ struct Mfma256F8S
 //   1024 no LDS-DMA in the loop (weight loads stay)   2048 no weight loads in the loop (LDS-DMA stays)
 //   8192 epilogue without global stores   16384 epilogue without arithmetic (conversion and stores only)
 //   4096 cycle stamps (s_memtime) at entry, first row block, end of the K loop and exit -> p.dbg[workgroup][wave][4]
-template <int PROBE>
+// ABSCALE: block-wise scales of both operands (GemmParams::sa / sb; one K tile = one 128-k scale block).  Every row block's
+// MFMAs then start from zero and their sums are folded into the accumulators with the block's a_scale * b_scale (one fused
+// multiply-add per accumulator register and K tile); the scales of the workgroup's two 128-row halves and of each wave's
+// 32 columns sit in two small LDS tables behind the C tile image, written in the prologue.
+template <int PROBE, bool ABSCALE = false>
 __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 {
     using T = Mfma256F8S;
@@ -189,6 +200,30 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
         return;
     }
 
+    [[maybe_unused]] const float* tab_a = (const float*)(lds + T::TAB_A);
+    [[maybe_unused]] const float* tab_b = (const float*)(lds + T::TAB_B) + wave * T::TAB_LD;
+    [[maybe_unused]] float s_lo = 0.f, s_hi = 0.f, s_lo_next = 0.f, s_hi_next = 0.f; // a_scale * b_scale of rows 0..127 / 128..255
+    if constexpr(ABSCALE)
+    {
+        // FNUZ bytes are multiplied as twice their value: their 2^-1 rides on the activation scales
+        const float half = p.a_scale != 0x7F7F7F7F ? 0.5f : 1.f;
+        const int kt0    = kz_begin / T::BK;
+        float* wa        = (float*)(lds + T::TAB_A);
+        float* wb        = (float*)(lds + T::TAB_B);
+        for(int i = threadIdx.x; i < 2 * (ntiles + 1); i += T::THREADS)
+        {
+            const int tt = min(i >> 1, ntiles - 1), h = i & 1;
+            const int mb = min(m0 + h * 128, p.M - 1) / p.bm;
+            wa[i]        = p.sa[(size_t)mb * p.ld_sa + kt0 + tt] * half;
+        }
+        for(int i = threadIdx.x; i < 8 * (ntiles + 1); i += T::THREADS)
+        {
+            const int wv = i / (ntiles + 1), tt = min(i % (ntiles + 1), ntiles - 1);
+            wb[wv * T::TAB_LD + i % (ntiles + 1)] = p.sb[(size_t)(kt0 + tt) + (size_t)((n0 + wv * 32) / p.bn) * p.ld_sb];
+        }
+        // (visible to every wave behind the prologue's barrier below)
+    }
+
     // ---- prologue: A(0), B(0), A(1), B(1), A(2); tile 0 complete and converted, first LEAD fragments fetched ----
     constexpr bool SPREAD = (PROBE & 64) != 0;
 #pragma unroll
@@ -232,6 +267,11 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
         convert_piece(wf[0], raw[0], std::integral_constant<int, 5>{});
         convert_piece(wf[0], raw[0], std::integral_constant<int, 6>{});
         convert_piece(wf[0], raw[0], std::integral_constant<int, 7>{});
+    }
+    if constexpr(ABSCALE)
+    {
+        const float sb0 = tab_b[0];
+        s_lo_next = tab_a[0] * sb0, s_hi_next = tab_a[1] * sb0;
     }
     read_a(0, 0, std::integral_constant<int, 0>{});
     read_a(0, 1, std::integral_constant<int, 1>{});
@@ -310,7 +350,25 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                         dma_a(a3, slot3, T::A_DMA - 1);
                 }
             }
-            if constexpr(!(PROBE & 16))
+            if constexpr(ABSCALE)
+            {
+                if constexpr(mt == 0)
+                    s_lo = s_lo_next, s_hi = s_hi_next;
+                if constexpr(mt == MT / 2)
+                {
+                    // the scales of tile t + 1 (the tables hold one spare entry past the last tile)
+                    const float sbn = tab_b[t + 1];
+                    s_lo_next = tab_a[2 * (t + 1)] * sbn, s_hi_next = tab_a[2 * (t + 1) + 1] * sbn;
+                }
+                const f4_t zero = {0.f, 0.f, 0.f, 0.f};
+                const f4_t t0   = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], zero, 1, 0, 0, 0, 0, 0);
+                const f4_t t1   = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], zero, 1, 0, 0, 0, 0, 0);
+                const float s   = mt < MT / 2 ? s_lo : s_hi;
+                const f4_t sv   = {s, s, s, s};
+                acc[0][mt]      = __builtin_elementwise_fma(t0, sv, acc[0][mt]);
+                acc[1][mt]      = __builtin_elementwise_fma(t1, sv, acc[1][mt]);
+            }
+            else if constexpr(!(PROBE & 16))
             {
                 // The plain (unscaled) form of the instruction: zero scale operands select v_mfma_f32_16x16x128_f8f6f4, which
                 // has no scale-load half and issues faster than v_mfma_scale_*; FNUZ activations get their 2^-1 after the loop.
@@ -335,7 +393,16 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
             if constexpr(!(PROBE & 1))
                 convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
             constexpr int ORDER = (PROBE >> 7) & 3; // (diagnostic: other placements of the conversion work)
-            if constexpr(ORDER == 0)
+            if constexpr(ABSCALE)
+            {
+                // (the conversion behind the first MFMA, the fused multiply-adds of both sums behind the second)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            else if constexpr(ORDER == 0)
             {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // the two fragment reads
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -404,7 +471,7 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 
     // FNUZ bytes were multiplied as the E4M3FN values of the same bits, i.e. twice their value: halve the sums (exact: a
     // power of two; the products inside the matrix core scale the same way, so the bits equal those of a 2^-1 block scale)
-    if constexpr(!(PROBE & 32))
+    if constexpr(!(PROBE & 32) && !ABSCALE)
         if(p.a_scale != 0x7F7F7F7F)
         {
 #pragma unroll
@@ -435,5 +502,6 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 }
 
 __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p) { f8s_kernel_body<0>(p); }
+__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256_abscale(const GemmParams p) { f8s_kernel_body<0, true>(p); }
 
 } // namespace wq

@@ -41,6 +41,10 @@ struct GemmParams
     int scale_group_shift; // log2(scale_group_k) when that is a power of two (small-M kernels), else -1
     int a_f8;          // small-M whole-image kernel only: a holds fp8 bytes (1: E4M3 FNUZ, 2: OCP E4M3FN; lda in bytes), widened
                        // to fp16 (exact) on their way into LDS; 0: a holds the 16-bit activations
+    // fp8 kernel, block-wise scales of both operands (both non-null; scale_block_k = 128 = the K tile): see GenericParams
+    const float* sa;
+    const float* sb;
+    int bm, bn, ld_sa, ld_sb;
     int b_preshuf;     // weights in the pre-shuffled order (1 KiB blocks of 64 k x 32 columns of packed int4 or x 16
                        // columns of int8; column-block pitch = 32 * ldb_bytes or 16 * ldb_bytes): 256-tile kernels only
 };
@@ -859,6 +863,11 @@ struct GenericParams
     int a_dtype, b_dtype; // wq_dtype
     EpilogueArgs epi;
     int scale_group_k, ld_scale; // > 0: group-wise scales, scale[(k / scale_group_k) * ld_scale + n]
+    // fp8 activations with block-wise scales of both operands (both non-null): a' = float(a) * sa[(m / bm) * ld_sa + k / bk],
+    // b' = float(q) * sb[k / bk + (n / bn) * ld_sb]
+    const float* sa;
+    const float* sb;
+    int bm, bn, bk, ld_sa, ld_sb;
 };
 
 // 8-bit weights (K, N) row-major (N contiguous, ld = ldb) -> (N, K) with K contiguous, the operand order of the
@@ -982,6 +991,13 @@ __global__ __launch_bounds__(256) void wq_gemm_generic(const GenericParams p)
             const uint8_t x = ((const uint8_t*)p.a)[m * p.a_sm + k * p.a_sk];
             va              = p.a_dtype == 8 /*WQ_F8_E4M3FN*/ ? f8_e4m3fn_to_f32(x) : f8_fnuz_to_f32(x);
             vb              = (float)q;
+            if(p.sa)
+            {
+                // example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:262-283: both operands are
+                // dequantised to fp32 (one rounding each) before the fp32 multiply-add
+                va = va * p.sa[(size_t)(m / p.bm) * p.ld_sa + k / p.bk];
+                vb = vb * p.sb[(size_t)(k / p.bk) + (size_t)(n / p.bn) * p.ld_sb];
+            }
         }
         acc += va * vb;
     }

@@ -89,6 +89,7 @@ struct Plan
 bool is16(int dt) { return dt == WQ_F16 || dt == WQ_BF16; }
 bool is_i4(int dt) { return dt == WQ_I4_PACKED || dt == WQ_I4_PRESHUFFLED; } // two nibbles per byte, either unit order
 bool is_preshuf(int dt) { return dt == WQ_I4_PRESHUFFLED || dt == WQ_I8_PRESHUFFLED; }
+bool has_block_scales(const wqgemm_problem* p) { return p->a_block_scale != nullptr || p->b_block_scale != nullptr; }
 
 // Epilogues of the floating-point family and the D vectors each one reads.
 int check_fp_epilogue(const wqgemm_problem* p)
@@ -182,6 +183,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         return fail(WQ_ERR_UNSUPPORTED, "split-K needs N and ldc to be multiples of 4");
 
     // ---- int8 x int8 requantised GEMM (example/14, client_example/09) ------------------------
+    if(p->a_dtype == WQ_I8 && has_block_scales(p))
+        return fail(WQ_ERR_UNSUPPORTED, "block-wise scales of both operands go with fp8 activations");
     if(p->a_dtype == WQ_I8)
     {
         const bool requant_epi = p->epilogue == WQ_EPI_ACT_MUL_CLAMP || p->epilogue == WQ_EPI_RELU_MUL_CLAMP ||
@@ -273,6 +276,25 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         if(p->ld_scale != 0 && p->ld_scale < p->N)
             return fail(WQ_ERR_INVALID, "ld_scale too small");
     }
+    // Block-wise scales of both operands (fp8 activations)
+    const bool ab_scaled = has_block_scales(p);
+    if(ab_scaled)
+    {
+        if(!p->a_block_scale || !p->b_block_scale)
+            return fail(WQ_ERR_INVALID, "block-wise scales come in pairs: a_block_scale and b_block_scale");
+        if(is16(p->a_dtype))
+            return fail(WQ_ERR_UNSUPPORTED, "block-wise scales of both operands go with fp8 activations (16-bit activations: scale_group_k)");
+        if(p->scale_block_m < 1 || p->scale_block_n < 1 || p->scale_block_k < 1)
+            return fail(WQ_ERR_INVALID, "scale_block_m / _n / _k must be positive");
+        const int kblocks = (p->K + p->scale_block_k - 1) / p->scale_block_k;
+        if(p->ld_a_scale < 0 || p->ld_b_scale < 0 || (p->ld_a_scale != 0 && p->ld_a_scale < kblocks) ||
+           (p->ld_b_scale != 0 && p->ld_b_scale < kblocks))
+            return fail(WQ_ERR_INVALID, "ld_a_scale / ld_b_scale must be 0 or at least ceil(K / scale_block_k) = %d", kblocks);
+        if(plan.partial)
+            return fail(WQ_ERR_UNSUPPORTED, "block-wise scales are not combined with k_batch or K slices");
+        if((uintptr_t)p->a_block_scale % 4 != 0 || (uintptr_t)p->b_block_scale % 4 != 0)
+            return fail(WQ_ERR_INVALID, "block scales are fp32: 4-byte aligned pointers");
+    }
     if(!slice)
     {
         // (a K-slice launch stores fp32 partials; its epilogue runs in wqgemm_reduce_finalize)
@@ -323,7 +345,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         // columns x 8192 k: 32.2 against 29.3 us -- one pass into the workspace is cheaper when there is one)
         const bool f8_fused = (size_t)p->M * (klen_all * 2 + 16) <= 40 * 1024 &&
                               (!have_workspace || (long)(p->N / 16) * klen_all <= 8L * 1000 * 1000);
-        const bool f8_image = !is16(p->a_dtype) && (have_workspace || f8_fused) && is_i4(p->b_dtype) && p->c_dtype == WQ_F16 &&
+        const bool f8_image = !is16(p->a_dtype) && !ab_scaled && (have_workspace || f8_fused) && is_i4(p->b_dtype) && p->c_dtype == WQ_F16 &&
                               p->K % 8 == 0 && !(p->flags & WQ_FLAG_PINGPONG);
         const bool eligible_f8 = f8_image && p->M <= 16 && !(p->flags & (WQ_FLAG_GENERIC | WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
                                  p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR && p->N % 64 == 0 && klen_all % ks == 0 &&
@@ -406,6 +428,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
     const bool fits_32bit = a_span * (is_f8 || p->a_dtype == WQ_I8 ? 1 : 2) <= 0x7FFFFFFFull && b_span <= 0x7FFFFFFFull;
     if(is_f8 && fits_32bit && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
        is_i4(p->b_dtype) && !(preshuf && (p->flags & WQ_FLAG_PINGPONG)) && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->N % 256 == 0 &&
+       (!ab_scaled || (p->scale_block_k == 128 && p->scale_block_m % 128 == 0 && p->scale_block_n % 32 == 0 && p->K / 128 <= 640 &&
+                       !(p->flags & WQ_FLAG_PINGPONG))) &&
        plan.k_begin % 128 == 0 && plan.k_per_z % 128 == 0 && (plan.k_end - plan.k_begin) % 128 == 0 &&
        p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
        (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
@@ -419,7 +443,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         // 8 bytes per slice and output at 8 TB/s (they mostly stay in the last-level cache) plus 3 us for the reduction.
         const int tiles = ((p->M + 255) / 256) * (p->N / 256);
         const int klen  = plan.k_end - plan.k_begin;
-        if(!plan.partial && tiles < 256)
+        if(!plan.partial && tiles < 256 && !ab_scaled)
         {
             double best = 1e30;
             int kb      = 1;
@@ -448,7 +472,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
     }
     // FNUZ bytes without that promise: exact in every encoding through an fp16 image of A in the workspace and
     // the fp16 kernels with a unit weight scale (falls back to the general kernel when no workspace is given).
-    if(p->a_dtype == WQ_F8_FNUZ && plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) &&
+    if(p->a_dtype == WQ_F8_FNUZ && !ab_scaled && plan.route == ROUTE_GENERIC && !(p->flags & WQ_FLAG_GENERIC) &&
        !plan.partial && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->b_layout == WQ_COL_MAJOR &&
        p->N % 128 == 0 && p->K % 64 == 0 && p->lda % 8 == 0 && p->ldb % b_row_align == 0 && p->ldc % 4 == 0 &&
        (uintptr_t)p->a % 8 == 0 && (uintptr_t)p->b % 16 == 0 && (uintptr_t)p->c % 16 == 0)
@@ -564,6 +588,20 @@ void set_scale_groups(wq::GemmParams& gp, const wqgemm_problem* p)
         gp.scale_group_shift = __builtin_ctz((unsigned)gp.scale_group_k);
 }
 
+template <typename Params>
+void set_block_scales(Params& gp, const wqgemm_problem* p)
+{
+    const bool on = p->a_block_scale && p->b_block_scale;
+    gp.sa         = on ? (const float*)p->a_block_scale : nullptr;
+    gp.sb         = on ? (const float*)p->b_block_scale : nullptr;
+    gp.bm = on ? p->scale_block_m : 1, gp.bn = on ? p->scale_block_n : 1;
+    const int kblocks = on ? (p->K + p->scale_block_k - 1) / p->scale_block_k : 1;
+    gp.ld_sa = on && p->ld_a_scale > 0 ? p->ld_a_scale : kblocks;
+    gp.ld_sb = on && p->ld_b_scale > 0 ? p->ld_b_scale : kblocks;
+    if constexpr(std::is_same_v<Params, wq::GenericParams>)
+        gp.bk = on ? p->scale_block_k : 1;
+}
+
 wq::EpilogueArgs epilogue_of(const wqgemm_problem* p)
 {
     wq::EpilogueArgs e;
@@ -648,6 +686,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.dbg          = g_dbg;
         gp.a_scale      = p->a_dtype == WQ_F8_FNUZ ? 0x7E7E7E7E : 0x7F7F7F7F;
         set_scale_groups(gp, p);
+        set_block_scales(gp, p);
         {
             // Tiles are dealt to the 8 XCDs in contiguous runs of nwg/8 (xcd_remap); inside a run the
             // walk covers group_m tile rows x (run / group_m) tile columns.  Pick the group that
@@ -830,6 +869,7 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         gp.epi     = epilogue_of(p);
         gp.scale_group_k = p->scale_group_k > 0 ? p->scale_group_k : 0;
         gp.ld_scale      = p->ld_scale > 0 ? p->ld_scale : p->N;
+        set_block_scales(gp, p);
         const dim3 grid((p->N + 15) / 16, (p->M + 15) / 16, plan.k_batch);
         hipLaunchKernelGGL(wq::wq_gemm_generic, grid, dim3(256), 0, s, gp);
     }
@@ -1228,7 +1268,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_I8_MFMA256 ? "wq_gemm_i8_mfma_256"
-             : plan.route == ROUTE_F8_MFMA256 ? "wq_gemm_f8_mfma_256"
+             : plan.route == ROUTE_F8_MFMA256 ? (has_block_scales(p) ? "wq_gemm_f8_mfma_256_abscale" : "wq_gemm_f8_mfma_256")
              : plan.route == ROUTE_SKINNY ? "wq_gemm_skinny"
              : plan.route == ROUTE_SKINNY_WS
                  ? ((size_t)p->M * ((plan.k_end - plan.k_begin) * 2 + 16) <= 40 * 1024 ? "wq_gemm_skinny_ws" : "wq_gemm_skinny_wsc")

@@ -143,6 +143,23 @@ typedef struct wqgemm_problem
      * ...) on the 128- and 256-tile matrix-core kernels; g a power of two >= 32 (packed int4) or >= 16 (int8) on the
      * small-M kernels.  k (and so the group index) counts from the start of the K range also for K slices and split-K. */
     int32_t scale_group_k, ld_scale;
+    /* Block-wise scales of BOTH operands, for fp8 activations (a_dtype WQ_F8_FNUZ / WQ_F8_E4M3FN; `scale` stays NULL):
+     * the problem of example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:58-75,126-152,262-283
+     * (DeviceGemmMultiD_ABScale, include/ck/tensor_operation/gpu/device/device_gemm_multiple_d_ab_scale.hpp) with int4 / int8
+     * weights in place of its fp8 weights.  Both non-NULL selects it:
+     *   a'(m, k) = float(a(m, k)) * a_block_scale[(m / scale_block_m) * ld_a_scale + k / scale_block_k]     (row-major)
+     *   b'(k, n) = float(q(k, n)) * b_block_scale[k / scale_block_k + (n / scale_block_n) * ld_b_scale]     (column-major,
+     *              the descriptor the example gives its B1 tensor under B0Layout = ColumnMajor)
+     *   C = epilogue( sum_k a'(m, k) * b'(k, n) ),  fp32 products and sums, k ascending.
+     * The general kernel evaluates exactly that (bit-exact with the reference's host loop).  The fp8 matrix-core kernel
+     * (scale_block_k = 128, scale_block_m a multiple of 128, scale_block_n a multiple of 32, no more than 640 K tiles)
+     * sums each 128-k block exactly on the matrix core and applies a_scale * b_scale to the block's sum: the same value up
+     * to fp32 rounding (identical when the scales are powers of two).  ld_a_scale >= ceil(K / scale_block_k),
+     * ld_b_scale >= ceil(K / scale_block_k); 0 = exactly that.  Not combined with k_batch / K slices. */
+    const void* a_block_scale;
+    const void* b_block_scale;
+    int32_t scale_block_m, scale_block_n, scale_block_k;
+    int32_t ld_a_scale, ld_b_scale;
 } wqgemm_problem;
 
 /* Library version string, e.g. "wqgemm 0.1 (gfx950)". */

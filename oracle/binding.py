@@ -93,6 +93,9 @@ class Checker:
         self._bf16_g = sig("gemm_bf16_i8_grouped", None,
                            [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + tail)
         self._f8 = sig("gemm_f8_i8_mm", None, [_u8p, _i8p, _f32p, _f32p, _u16p] + [C.c_int] * 7 + tail)
+        # (the plain-C port takes one more int, e4m3fn, before the thread count; the reference shim knows FNUZ only)
+        self._f8_ab = sig("gemm_f8_i8_abscale", None, [_u8p, _i8p, _f32p, _f32p, _u16p] + [C.c_int] * 12 +
+                          ([C.c_int] if self._threaded else []) + tail)
         self._bf16_dmat = sig("gemm_bf16_i8_dmat", None,
                               [_u16p, _i8p, C.c_void_p, _u16p] + [C.c_int] * 8 +
                               [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + tail)
@@ -198,6 +201,18 @@ class Checker:
     def gemm_f8_i8_mm(self, a, b, d0, d1, M, N, K, lda, ldb, lde, fastgelu, nthreads=None) -> np.ndarray:
         e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.uint16)
         self._f8(a.ravel(), b.ravel(), d0, d1, e, M, N, K, lda, ldb, lde, int(fastgelu), *self._t(nthreads))
+        return e
+
+    def gemm_f8_i8_abscale(self, a, b, sa, sb, M, N, K, lda, ldb, lde, block, ld_sa, ld_sb, e_bf16=False, e4m3fn=False,
+                           nthreads=None) -> np.ndarray:
+        """fp8 A x int8-held weights with block-wise scales of both operands (example/65's fp8_ab_scale host check):
+        block = (bm, bn, bk); sa row-major (M / bm, K / bk), sb column-major (K / bk, N / bn).  Returns 16-bit patterns."""
+        if e4m3fn and not self._threaded:
+            raise ValueError("the reference's f8_t is E4M3 FNUZ only")
+        e = np.zeros(1 + (M - 1) * lde + (N - 1), dtype=np.uint16)
+        extra = [int(e4m3fn)] if self._threaded else []
+        self._f8_ab(a.ravel(), b.ravel(), np.ascontiguousarray(sa, np.float32).ravel(), np.ascontiguousarray(sb, np.float32).ravel(),
+                    e, M, N, K, lda, ldb, lde, *block, ld_sa, ld_sb, int(e_bf16), *extra, *self._t(nthreads))
         return e
 
     # -- port-only helpers --------------------------------------------------------------------

@@ -450,4 +450,34 @@ void ckref_gemm_f8_i8_mm(const uint8_t* a, const int8_t* b, const float* d0, con
         }
 }
 
+// example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:262-283, the host verification of the
+// block-scaled problem, run through the reference's own pieces: type_convert<float>(f8_t), the fp32 dequantisation loops as
+// the example writes them, ReferenceGemm<float, float, float, float>, type_convert to the output type.  B0 is int8 here
+// (int4 / int8 weights); a1 row-major (ld_sa), b1 column-major (ld_sb) as the example's descriptors (:126-139).
+void ckref_gemm_f8_i8_abscale(const uint8_t* a, const int8_t* b, const float* sa, const float* sb, uint16_t* e, int M, int N,
+                              int K, int lda, int ldb, int lde, int bm, int bn, int bk, int ld_sa, int ld_sb, int e_bf16)
+{
+    auto ta = load2<f8_t>(a, M, K, lda, 1);
+    auto tb = load2<int8_t>(b, K, N, 1, ldb);
+    Tensor<float> a_m_k(desc2(M, K, K, 1)), b_k_n(desc2(K, N, N, 1)), c_m_n(desc2(M, N, N, 1));
+    for(int m = 0; m < M; m++)
+        for(int k = 0; k < K; k++)
+            a_m_k(m, k) = ck::type_convert<float>(ta(m, k)) * sa[static_cast<size_t>(m / bm) * ld_sa + k / bk];
+    for(int n = 0; n < N; n++)
+        for(int k = 0; k < K; k++)
+            b_k_n(k, n) = ck::type_convert<float>(tb(k, n)) * sb[static_cast<size_t>(k / bk) + static_cast<size_t>(n / bn) * ld_sb];
+    using Ref = ck::tensor_operation::host::ReferenceGemm<float, float, float, float, PT, PT, PT>;
+    auto ref  = Ref{};
+    auto inv  = ref.MakeInvoker();
+    inv.Run(ref.MakeArgument(a_m_k, b_k_n, c_m_n, PT{}, PT{}, PT{}));
+    for(int m = 0; m < M; ++m)
+        for(int n = 0; n < N; ++n)
+        {
+            if(e_bf16)
+                e[static_cast<size_t>(m) * lde + n] = bits_to<uint16_t>(ck::type_convert<ck::bhalf_t>(c_m_n(m, n)));
+            else
+                e[static_cast<size_t>(m) * lde + n] = bits_to<uint16_t>(ck::type_convert<ck::half_t>(c_m_n(m, n)));
+        }
+}
+
 } // extern "C"

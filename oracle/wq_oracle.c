@@ -639,6 +639,56 @@ void wqo_gemm_f8_i8_mm(const uint8_t* a, const int8_t* b, const float* d0, const
     parallel_mn(f8_i8_mm_mn, &x, M, N, nthreads);
 }
 
+/* example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:262-283 (host verification of
+ * DeviceGemmMultiD_ABScale): both operands are dequantised to fp32 first --
+ *   a'(m,k) = float(a0(m,k)) * a1(m / bm, k / bk)      a1 row-major, ld_sa    (A0Layout = RowMajor descriptor, :126-133)
+ *   b'(k,n) = float(b0(k,n)) * b1(k / bk, n / bn)      b1 column-major: (kb, nb) at kb + nb * ld_sb (B0Layout = ColumnMajor, :135-139)
+ * -- then ReferenceGemm<float, float, float, float> (fp32 multiply and add, k ascending) and the conversion of the sum to
+ * the output type (CDEElementOp = PassThrough, :50-54).  Here b0 holds int4 / int8 weights in int8 (K contiguous per
+ * column) instead of the example's fp8 bytes; e_bf16 != 0: bf16 output (the example's EDataType; truncating convert),
+ * else fp16.  e4m3fn != 0: the activation bytes are OCP E4M3 instead of the reference's FNUZ. */
+typedef struct
+{
+    const uint8_t* a;
+    const int8_t* b;
+    const float* sa;
+    const float* sb;
+    uint16_t* e;
+    int K, lda, ldb, lde, bm, bn, bk, ld_sa, ld_sb, e_bf16, e4m3fn;
+} f8_ab_ctx;
+
+static float wqo_f8_e4m3fn_to_f32_local(uint8_t x)
+{
+    if((x & 0x7F) == 0x7F)
+        return NAN;
+    const int e = (x >> 3) & 15, m = x & 7;
+    const float v = e == 0 ? (float)m * 0.001953125f : ldexpf((float)(8 + m), e - 10);
+    return (x & 0x80) ? -v : v;
+}
+
+static void f8_ab_mn(void* p, int m, int n)
+{
+    const f8_ab_ctx* x = (const f8_ab_ctx*)p;
+    float acc          = 0.f;
+    for(int k = 0; k < x->K; ++k)
+    {
+        const uint8_t byte = x->a[(size_t)m * x->lda + k];
+        const float a0     = x->e4m3fn ? wqo_f8_e4m3fn_to_f32_local(byte) : wqo_f8_fnuz_to_f32(byte);
+        const float av     = a0 * x->sa[(size_t)(m / x->bm) * x->ld_sa + k / x->bk];
+        const float bv     = (float)x->b[(size_t)n * x->ldb + k] * x->sb[(size_t)(k / x->bk) + (size_t)(n / x->bn) * x->ld_sb];
+        acc += av * bv;
+    }
+    x->e[(size_t)m * x->lde + n] = x->e_bf16 ? wqo_f32_to_bf16(acc) : wqo_f32_to_f16(acc);
+}
+
+void wqo_gemm_f8_i8_abscale(const uint8_t* a, const int8_t* b, const float* sa, const float* sb, uint16_t* e, int M, int N, int K,
+                            int lda, int ldb, int lde, int bm, int bn, int bk, int ld_sa, int ld_sb, int e_bf16, int e4m3fn,
+                            int nthreads)
+{
+    f8_ab_ctx x = {a, b, sa, sb, e, K, lda, ldb, lde, bm, bn, bk, ld_sa, ld_sb, e_bf16, e4m3fn};
+    parallel_mn(f8_ab_mn, &x, M, N, nthreads);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* split-K arithmetic                                                                          */
 /* ------------------------------------------------------------------------------------------- */

@@ -313,6 +313,41 @@ def splitk_shapes(ref) -> dict:
     return out
 
 
+def abscale_cases(ref) -> dict:
+    """fp8 activations x int4 / int8 weights with block-wise scales of both operands: outputs of the reference's own host
+    check of DeviceGemmMultiD_ABScale (example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:262-283:
+    type_convert<float>(f8_t), fp32 dequantisation of both operands, ReferenceGemm<float, float, float, float>, convert).
+    A seed of its own."""
+    rng = np.random.default_rng(20250128)
+    out = {}
+
+    def case(tag, M, N, K, block, lo, hi, e_bf16, pad=(0, 0), pow2=False):
+        bm, bn, bk = block
+        kb = (K + bk - 1) // bk
+        a = rng.integers(0, 256, (M, K)).astype(np.uint8)
+        a[a == 0x80] = 0                      # FNUZ NaN
+        if pow2:                              # exact set: activations in {-2 .. 2} (FNUZ bytes), power-of-two scales
+            a = np.array([0xC8, 0xC0, 0x00, 0x40, 0x48], np.uint8)[rng.integers(0, 5, (M, K))]
+        q = rng.integers(lo, hi + 1, (N, K)).astype(np.int8)
+        ld_sa, ld_sb = kb + pad[0], kb + pad[1]
+        shape_a, shape_b = ((M + bm - 1) // bm, ld_sa), ((N + bn - 1) // bn, ld_sb)
+        if pow2:
+            sa = np.exp2(rng.integers(-3, 2, shape_a)).astype(np.float32)
+            sb = np.exp2(rng.integers(-3, 2, shape_b)).astype(np.float32)
+        else:
+            sa = rng.uniform(0.0, 1.0, shape_a).astype(np.float32)
+            sb = rng.uniform(0.0, 1.0, shape_b).astype(np.float32)
+        out[f"{tag}_shape"] = np.array([M, N, K, bm, bn, bk, ld_sa, ld_sb, int(e_bf16)], np.int32)
+        out[f"{tag}_a"], out[f"{tag}_q"], out[f"{tag}_sa"], out[f"{tag}_sb"] = a, q, sa, sb
+        out[f"{tag}_e"] = ref.gemm_f8_i8_abscale(a, q, sa, sb, M, N, K, K, K, N, block, ld_sa, ld_sb, e_bf16=e_bf16)
+
+    case("ab128_i4_bf16", 256, 256, 512, (128, 128, 128), -8, 7, True)
+    case("ab128_i4_f16_pow2", 256, 512, 384, (128, 128, 128), -8, 7, False, pow2=True)
+    case("ab_small_blocks_i8", 40, 48, 300, (16, 32, 128), -128, 127, False, pad=(1, 2))
+    case("ab_ragged_i4", 33, 20, 200, (8, 4, 64), -8, 7, True, pad=(0, 3))
+    return out
+
+
 def main() -> None:
     ref = binding.load_ref()
     if ref is None:
@@ -320,7 +355,8 @@ def main() -> None:
     np.savez_compressed(os.path.join(OUT, "scalars.npz"), **scalars(ref))
     np.savez_compressed(os.path.join(OUT, "gemm_cases.npz"), **gemm_cases(ref))
     np.savez_compressed(os.path.join(OUT, "splitk_shapes.npz"), **splitk_shapes(ref))
-    for f in ("scalars.npz", "gemm_cases.npz", "splitk_shapes.npz"):
+    np.savez_compressed(os.path.join(OUT, "abscale_cases.npz"), **abscale_cases(ref))
+    for f in ("scalars.npz", "gemm_cases.npz", "splitk_shapes.npz", "abscale_cases.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
 
 

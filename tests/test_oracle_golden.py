@@ -339,3 +339,17 @@ def test_splitk_reference_shapes_golden(port, tag):
         q = np.ascontiguousarray(b.T)      # (N, K): K contiguous per column
         got = port.gemm_bf16_i8(g[f"{tag}_a_{kind}"], q, None, M, N, K, K, 1, K, N, 0)
         np.testing.assert_array_equal(got, g[f"{tag}_c_{kind}"])
+
+
+ABSCALE_TAGS = ["ab128_i4_bf16", "ab128_i4_f16_pow2", "ab_small_blocks_i8", "ab_ragged_i4"]
+
+
+@pytest.mark.parametrize("tag", ABSCALE_TAGS)
+def test_f8_block_scaled_gemm_golden(port, tag):
+    """fp8 activations x int4 / int8 weights with block-wise scales of both operands: the plain-C checker against outputs of
+    the reference's own host check (example/65 ..._fp8_ab_scale.cpp:262-283), bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "abscale_cases.npz"))
+    M, N, K, bm, bn, bk, ld_sa, ld_sb, bf = (int(v) for v in g[f"{tag}_shape"])
+    got = port.gemm_f8_i8_abscale(g[f"{tag}_a"], g[f"{tag}_q"], g[f"{tag}_sa"], g[f"{tag}_sb"], M, N, K, K, K, N, (bm, bn, bk),
+                                  ld_sa, ld_sb, e_bf16=bool(bf))
+    np.testing.assert_array_equal(got, g[f"{tag}_e"])

@@ -99,3 +99,24 @@ def test_grouped_scales_bf16_random(port, ref):
         d0 = (rng.uniform(-0.5, 0.5, N).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
         np.testing.assert_array_equal(port.gemm_bf16_i8_grouped(a, b, s, M, N, K, K, 1, K, N, ep, gk, N, d0),
                                       ref.gemm_bf16_i8_grouped(a, b, s, M, N, K, K, 1, K, N, ep, gk, N, d0))
+
+
+def test_f8_block_scaled_random(port, ref):
+    """Block-wise scales of both operands (example/65's fp8_ab_scale host check): port == reference on random shapes,
+    block sizes and paddings."""
+    rng = np.random.default_rng(65)
+    for _ in range(12):
+        M, N, K = (int(v) for v in rng.integers(1, 70, 3))
+        K = max(K, 2)
+        block = tuple(int(v) for v in rng.choice([1, 4, 16, 32, 128], 3))
+        kb = (K + block[2] - 1) // block[2]
+        ld_sa, ld_sb = kb + int(rng.integers(0, 3)), kb + int(rng.integers(0, 3))
+        a = rng.integers(0, 256, (M, K)).astype(np.uint8)
+        a[a == 0x80] = 0
+        q = rng.integers(-128, 128, (N, K)).astype(np.int8)
+        sa = rng.uniform(-1, 1, ((M + block[0] - 1) // block[0], ld_sa)).astype(np.float32)
+        sb = rng.uniform(-1, 1, ((N + block[1] - 1) // block[1], ld_sb)).astype(np.float32)
+        for bf in (False, True):
+            x = port.gemm_f8_i8_abscale(a, q, sa, sb, M, N, K, K, K, N, block, ld_sa, ld_sb, e_bf16=bf)
+            y = ref.gemm_f8_i8_abscale(a, q, sa, sb, M, N, K, K, K, N, block, ld_sa, ld_sb, e_bf16=bf)
+            np.testing.assert_array_equal(x, y)
