@@ -1231,8 +1231,9 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
     else if(plan.route == ROUTE_F8_MFMA256)
         snprintf(buf, n,
                  "DeviceGemmMultiplyMultiply_WeightQuant_Mfma_gfx950<512, 256, 256, 128, 16x16x128_f8f6f4, %s, %s, %s, "
-                 "LdsDmaA, DirectB, ConvertInRegister, KBatch%d>",
-                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch);
+                 "LdsDmaA, DirectB, ConvertInRegister, KBatch%d%s>",
+                 dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch,
+                 has_block_scales(p) ? ", ABScalePer128K" : "");
     else if(plan.route == ROUTE_SKINNY_WS)
         snprintf(buf, n, "DeviceFpAintBGemm_SmallM_gfx950<256, 16, 16, 16x16x32, %s, %s, %s, StreamB, WavesSplitK>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype));

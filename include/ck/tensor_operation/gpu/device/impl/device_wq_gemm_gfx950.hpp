@@ -20,6 +20,10 @@
 //        stands where DeviceGemmMultiD_Xdl_CShuffle_V3<f8,f8,(f32,f32)> does
 //        (impl/device_gemm_multiple_d_xdl_cshuffle_v3.hpp)
 //
+//   DeviceGemmMultiD_ABScale_WeightQuant_gfx950 : DeviceGemmMultipleD_ABScale (example/65 ..._fp8_ab_scale)
+//        stands where DeviceGemmMultiD_ABScale_Xdl_CShuffle_V3<f8, f32, f8, f32> does
+//        (impl/device_gemm_multiple_d_xdl_cshuffle_v3_ab_scale.hpp), with int4 / int8 weights in place of fp8 ones
+//
 //   DeviceGemmV2R1_WeightQuant_gfx950    : DeviceGemmV2R1          (example/35 gemm_xdl_splitk_reduce_bf16A_i8B)
 //        stands where DeviceGemm_Xdl_CShuffleV3R1<bf16, int8> does
 //        (impl/device_gemm_xdl_cshuffle_v3r1.hpp:28-700): KSplit before the functors, fp32 slabs in the
@@ -50,6 +54,7 @@
 #include "ck/tensor_operation/gpu/device/tensor_layout.hpp"
 #include "ck/tensor_operation/gpu/device/device_gemm_dequantB.hpp"
 #include "ck/tensor_operation/gpu/device/device_gemm_multiple_d.hpp"
+#include "ck/tensor_operation/gpu/device/device_gemm_multiple_d_ab_scale.hpp"
 #include "ck/tensor_operation/gpu/device/device_gemm_multiple_abd.hpp"
 #include "ck/tensor_operation/gpu/device/device_gemm_splitk.hpp"
 #include "ck/tensor_operation/gpu/device/device_gemm_v2.hpp"
@@ -969,6 +974,78 @@ struct DeviceGemmMultiplyMultiply_Int4Values_gfx950
         return std::string("DeviceGemmMultiplyMultiply_Int4Values_gfx950<") +
                (std::is_same_v<ADataType, ck::wq_f8_e4m3fn_t> ? "F8_E4M3FN" : AssumeNoFnuzSpecials ? "F8_FNUZ_NoSpecials" : "F8_FNUZ") +
                ", int4 per byte -> I4x2 packed per Run>";
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// E[M,N] = convert( sum_k (float(A[m,k]) * a_scale[m / ScaleBlockM][k / ScaleBlockK])
+//                        * (float(B[k,n]) * b_scale[k / ScaleBlockK][n / ScaleBlockN]) )
+// fp8 activations, int4 (packed / pre-shuffled) or int8 weights, fp32 block scales of BOTH operands -- the problem
+// of example/65_gemm_multiply_multiply/gemm_multiply_multiply_xdl_fp8_ab_scale.cpp:58-75,126-152,262-283 with
+// weight-quantized B.  a_scale is row-major (ceil(M/ScaleBlockM), ceil(K/ScaleBlockK)), b_scale column-major
+// (ceil(K/ScaleBlockK), ceil(N/ScaleBlockN)), both densely packed (leading dimension ceil(K/ScaleBlockK), as the
+// example's Scale_Stride_AM / Scale_Stride_BN).  With 128-k blocks (ScaleBlockM a multiple of 128, ScaleBlockN of 32)
+// the fp8 matrix-core kernel scales each 128-k block sum in registers; other block shapes run on the general kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename ALayout, typename BLayout, typename ELayout, typename ADataType, typename BDataType,
+          typename EDataType, index_t ScaleBlockM, index_t ScaleBlockN, index_t ScaleBlockK,
+          bool AssumeNoFnuzSpecials = false>
+struct DeviceGemmMultiD_ABScale_WeightQuant_gfx950
+    : public DeviceGemmMultipleD_ABScale<ALayout, BLayout, ck::Tuple<>, ELayout, ADataType, float, BDataType, float,
+                                         ck::Tuple<>, EDataType, ScaleBlockM, ScaleBlockN, ScaleBlockK,
+                                         element_wise::PassThrough, element_wise::PassThrough, element_wise::PassThrough>
+{
+    using Argument    = wq_detail::Argument;
+    using Invoker     = wq_detail::Invoker;
+    using PassThrough = element_wise::PassThrough;
+
+    static Argument MakeArgument(const void* p_a, const void* p_b, std::array<const void*, 0>, void* p_e, index_t M,
+                                 index_t N, index_t K, index_t StrideA, index_t StrideB, std::array<index_t, 0>,
+                                 index_t StrideE, const void* p_a_scale, const void* p_b_scale, PassThrough,
+                                 PassThrough, PassThrough)
+    {
+        Argument arg;
+        wqgemm_problem& p = arg.prob;
+        p.a_dtype         = wq_detail::dtype_of<ADataType>::value;
+        p.b_dtype         = wq_detail::dtype_of<BDataType>::value;
+        p.scale_dtype     = WQ_F32;
+        p.c_dtype         = wq_detail::dtype_of<EDataType>::value;
+        p.a_layout        = wq_detail::layout_of<ALayout>();
+        p.b_layout        = wq_detail::layout_of<BLayout>();
+        p.c_layout        = wq_detail::layout_of<ELayout>();
+        p.M = M, p.N = N, p.K = K;
+        p.lda = StrideA, p.ldb = StrideB, p.ldc = StrideE;
+        p.a = p_a, p.b = p_b, p.c = p_e;
+        p.epilogue      = WQ_EPI_PASSTHROUGH;
+        p.k_batch       = 1;
+        p.flags         = AssumeNoFnuzSpecials ? WQ_FLAG_F8_NO_SPECIALS : 0;
+        p.a_block_scale = p_a_scale, p.b_block_scale = p_b_scale;
+        p.scale_block_m = ScaleBlockM, p.scale_block_n = ScaleBlockN, p.scale_block_k = ScaleBlockK;
+        p.ld_a_scale = p.ld_b_scale = 0; // densely packed
+        return arg;
+    }
+    static Invoker MakeInvoker() { return Invoker{"DeviceGemmMultiD_ABScale_WeightQuant_gfx950"}; }
+    static bool IsSupportedArgument(const Argument& arg) { return wq_detail::supported(arg.prob); }
+    bool IsSupportedArgument(const BaseArgument* p_arg) override
+    {
+        return IsSupportedArgument(*dynamic_cast<const Argument*>(p_arg));
+    }
+    std::unique_ptr<BaseArgument> MakeArgumentPointer(const void* p_a, const void* p_b, std::array<const void*, 0> p_ds,
+                                                      void* p_e, const index_t M, const index_t N, const index_t K,
+                                                      const index_t StrideA, const index_t StrideB,
+                                                      const std::array<index_t, 0> StrideDs, const index_t StrideE,
+                                                      const void* p_a_scale, const void* p_b_scale, PassThrough a_op,
+                                                      PassThrough b_op, PassThrough cde_op) override
+    {
+        return std::make_unique<Argument>(MakeArgument(p_a, p_b, p_ds, p_e, M, N, K, StrideA, StrideB, StrideDs, StrideE,
+                                                       p_a_scale, p_b_scale, a_op, b_op, cde_op));
+    }
+    std::unique_ptr<BaseInvoker> MakeInvokerPointer() override { return std::make_unique<Invoker>(MakeInvoker()); }
+    std::string GetTypeString() const override
+    {
+        return std::string("DeviceGemmMultiD_ABScale_WeightQuant_gfx950<") +
+               (std::is_same_v<ADataType, ck::wq_f8_e4m3fn_t> ? "F8_E4M3FN" : AssumeNoFnuzSpecials ? "F8_FNUZ_NoSpecials" : "F8_FNUZ") +
+               ", " + std::to_string(ScaleBlockM) + "x" + std::to_string(ScaleBlockN) + "x" + std::to_string(ScaleBlockK) + ">";
     }
 };
 

@@ -470,6 +470,24 @@ struct DeviceGemmMultipleD : public BaseOperator
     virtual std::unique_ptr<BaseInvoker> MakeInvokerPointer() = 0;
 };
 
+// include/ck/tensor_operation/gpu/device/device_gemm_multiple_d_ab_scale.hpp:23-63
+template <typename ALayout, typename BLayout, typename DsLayout, typename ELayout, typename ADataType,
+          typename AScaleType, typename BDataType, typename BScaleType, typename DsDataType, typename EDataType,
+          index_t ScaleBlockM, index_t ScaleBlockN, index_t ScaleBlockK, typename AElementwiseOperation,
+          typename BElementwiseOperation, typename CDEElementwiseOperation>
+struct DeviceGemmMultipleD_ABScale : public BaseOperator
+{
+    static constexpr index_t NumDTensor = DsDataType::Size();
+    virtual std::unique_ptr<BaseArgument>
+    MakeArgumentPointer(const void* p_a, const void* p_b, std::array<const void*, NumDTensor> p_ds, void* p_e,
+                        const ck::index_t M, const ck::index_t N, const ck::index_t K, const ck::index_t StrideA,
+                        const ck::index_t StrideB, const std::array<ck::index_t, NumDTensor> StrideDs,
+                        const ck::index_t StrideE, const void* p_a_scale, const void* p_b_scale,
+                        AElementwiseOperation a_element_op, BElementwiseOperation b_element_op,
+                        CDEElementwiseOperation cde_element_op) = 0;
+    virtual std::unique_ptr<BaseInvoker> MakeInvokerPointer() = 0;
+};
+
 template <typename AsLayout, typename BsLayout, typename DsLayout, typename ELayout, typename AsDataType,
           typename BsDataType, typename DsDataType, typename EDataType, typename AElementwiseOperation,
           typename BElementwiseOperation, typename CDEElementwiseOperation>

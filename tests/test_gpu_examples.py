@@ -154,6 +154,16 @@ def test_fp8_int4_multiply_multiply_example(fmt, gelu, init):
     assert ("16x16x128_f8f6f4" in r.stdout) == (fmt != 0) and "Mfma" in r.stdout
 
 
+@pytest.mark.parametrize("fmt,init", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_fp8_int4_ab_scale_example(fmt, init):
+    """example/65's block-scaled flow (fp8 A with a scale per 128 x 128 block, weights with a scale per 128 x 128 block,
+    host check on operands scaled to fp32): bit-exact on integer values with power-of-two scales (init 1), within the
+    example's 5e-2 otherwise; both fp8 encodings, a partial last row tile."""
+    r = _run(os.path.join(EX, "example_gemm_ab_scale_fp8_int4_gfx950"), 1, init, 1, 640, 768, 1024, fmt)
+    assert r.returncode == 0 and "verification: PASS" in r.stdout, r.stdout + r.stderr
+    assert "16x16x128_f8f6f4" in r.stdout, r.stdout
+
+
 def test_reference_client_example09_source_dropin():
     """CK's client_example/09_quantization/gemm_quantization.cpp, compiled unmodified, must find the gfx950
     operator through CK's own DeviceOperationInstanceFactory (the add_device_* symbols come from

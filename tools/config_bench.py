@@ -117,6 +117,21 @@ def main():
             ws_t = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
             emit(f"C5 fp8 x int4 {M}x{N}x{K} MultiplyMultiply+FastGelu ({tag})", arith, p, ws_t, M, N, K, nbytes)
 
+    # fp8 x int4 with a scale per 128 x 128 block of both operands (example/65's ..._fp8_ab_scale shape, bf16 out)
+    for (M, N, K) in ((4096, 4096, 4096), (3840, 4096, 4096)):
+        a = (torch.randint(24, 88, (M, K), generator=g, device=dev, dtype=torch.int16) +
+             128 * torch.randint(0, 2, (M, K), generator=g, device=dev, dtype=torch.int16)).to(torch.uint8)
+        b = packed(N, K)
+        sa = torch.rand(((M + 127) // 128, K // 128), generator=g, device=dev)
+        sb = torch.rand((N // 128, K // 128), generator=g, device=dev)
+        c = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        nbytes = M * K + K * N // 2 + 4 * (sa.numel() + sb.numel()) + 2 * M * N
+        for dt, flags, tag in ((capi.F8_E4M3FN, 0, "E4M3FN"), (capi.F8_FNUZ, capi.FLAG_F8_NO_SPECIALS, "FNUZ, no special encodings")):
+            p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=dt, c_dtype=capi.BF16,
+                                     flags=flags, a_block_scale=sa.data_ptr(), b_block_scale=sb.data_ptr(),
+                                     scale_block=(128, 128, 128))
+            emit(f"fp8 x int4 {M}x{N}x{K}, 128x128x128 block scales of A and B ({tag})", "f8", p, None, M, N, K, nbytes)
+
     if args.out:
         with open(args.out, "w") as fh:
             for line in lines:
