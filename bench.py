@@ -107,11 +107,11 @@ def cpu_baseline_leg(a, q, s, c_gpu, M, N, K, budget_s=12.0):
     }
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, config="C2"):
     """HBM bytes per launch of `kernel` from the committed counter summary (separate rocprofv3 --pmc passes for
     FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as gfx950 requires; tools/pmc_summary.py), or None when the
     summary is absent or belongs to another kernel.  Counters cannot be collected from inside this process."""
-    for name in PMC_SUMMARIES:
+    for name in PMC_SUMMARIES.get(config, ()):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as fh:
@@ -125,7 +125,9 @@ def pmc_traffic(kernel):
 
 
 PEAK_8BIT_MFMA_TFLOPS = 5000.0  # dense fp8 / int8 MFMA peak of MI355X
-PMC_SUMMARIES = ("r2_mfma256_preshuffled_pmc.json", "r2_mfma256_pmc.json", "r1_mfma256_pmc.json")  # newest first
+# counter summaries per configuration (each taken on that configuration's shape and weight order), newest first
+PMC_SUMMARIES = {"C2": ("r3_c2_pmc.json", "r2_mfma256_preshuffled_pmc.json", "r2_mfma256_pmc.json", "r1_mfma256_pmc.json"),
+                 "C3": ("r3_c3_pmc.json",), "C5": ("r3_f8_pmc.json",)}
 
 
 def _cpu_cores():
@@ -350,7 +352,7 @@ def run_single(args):
     tflops = flops * args.steps / wall / 1e12
     kern_tflops = flops / (kern_ms * 1e-3) / 1e12
     nbytes = w["bytes"]
-    traffic, traffic_source = pmc_traffic(capi.kernel_name(p)) if args.config == "C2" else (None, None)
+    traffic, traffic_source = pmc_traffic(capi.kernel_name(p), args.config)
     out = {
         "metric": METRICS[args.config],
         "value": tflops,
@@ -366,7 +368,11 @@ def run_single(args):
         "dtype": w["dtype"],
         "data": "synthetic",
         "config": {"workload": w["workload"], "baseline_config": args.config,
-                   "M": M, "N": N, "K": K, "kernel": capi.kernel_name(p), "instance": capi.type_string(p)},
+                   "M": M, "N": N, "K": K, "kernel": capi.kernel_name(p), "instance": capi.type_string(p),
+                   # the order the weight bytes are stored in: a one-off offline re-layout of the packed / int8 matrix
+                   # (same bytes, same output bits); the plain order is timed beside it for C2 (packed_weights_tflops)
+                   "weights_layout": {capi.I4_PRESHUFFLED: "I4_PRESHUFFLED", capi.I8_PRESHUFFLED: "I8_PRESHUFFLED",
+                                      capi.I4_PACKED: "I4_PACKED", capi.I8: "I8"}.get(p.b_dtype, str(p.b_dtype))},
         "hbm_gbps_algorithmic": nbytes / (kern_ms * 1e-3) / 1e9,
         "hbm_frac_of_peak": nbytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
         "roofline": {"bound": "mfma", "achieved": kern_tflops, "peak": w["peak"],
