@@ -28,7 +28,8 @@ d0 = torch.rand((N,), generator=g, device=dev)
 d1 = torch.rand((M,), generator=g, device=dev)
 c = torch.empty((M, N), dtype=torch.float16, device=dev)
 p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_E4M3FN, b_dtype=bdt, c_dtype=capi.F16,
-                         epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU, d0=d0.data_ptr(), d1=d1.data_ptr())
+                         epilogue=capi.EPI_MULTIPLY_MULTIPLY_FASTGELU, d0=d0.data_ptr(), d1=d1.data_ptr(),
+                         flags=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for _ in range(n):
     capi.launch(p, None, sp)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--N", type=int, default=28672)
     ap.add_argument("--K", type=int, default=8192)
     ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--flags", type=int, default=0, help="wqgemm_problem.flags (kernel variants)")
     args = ap.parse_args()
     M, N, K = args.M, args.N, args.K
     dev = torch.device("cuda", 0)
@@ -59,7 +60,7 @@ def main():
                 b, bdt = b2, capi.I8_PRESHUFFLED
         c = torch.empty((M, N), dtype=adt, device=dev)
         p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K,
-                                 a_dtype=capi.F16 if args.a == "f16" else capi.BF16, b_dtype=bdt)
+                                 a_dtype=capi.F16 if args.a == "f16" else capi.BF16, b_dtype=bdt, flags=args.flags)
         nbytes = 2 * M * K + bb + 2 * N + 2 * M * N
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     wsb = capi.workspace_bytes(p)
