@@ -36,7 +36,8 @@ def bits_to_f32(bits: np.ndarray, dtype: int) -> np.ndarray:
 def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b_dtype=capi.I4_PACKED,
                 lda=None, ldb=None, ldc=None, epilogue=capi.EPI_PASSTHROUGH, d0=None, d1=None,
                 k_batch=1, expect_kernel=None, b_layout=capi.COL_MAJOR, flags=0, use_workspace=True, ldd0=0, ldd1=0,
-                scale_group_k=0, ld_scale=0):
+                scale_group_k=0, ld_scale=0, a_block_scale=None, b_block_scale=None, scale_block=(128, 128, 128), ld_a_scale=0,
+                ld_b_scale=0, c_dtype=None):
     """Run one fpAintB GEMM through the C ABI; returns the (M, ldc) uint16 output bits."""
     a_t = dev(a_bits)
     b_t = b_dev_bytes if isinstance(b_dev_bytes, torch.Tensor) else dev(b_dev_bytes)
@@ -49,13 +50,18 @@ def run_fpaintb(a_bits, b_dev_bytes, scale_bits, M, N, K, *, a_dtype=capi.F16, b
     d0_t = dev(d0) if d0 is not None else None
     d1_t = dev(d1) if d1 is not None else None
     keep += [d0_t, d1_t]
+    sa_t = dev(np.ascontiguousarray(a_block_scale, np.float32)) if a_block_scale is not None else None
+    sb_t = dev(np.ascontiguousarray(b_block_scale, np.float32)) if b_block_scale is not None else None
+    keep += [sa_t, sb_t]
     p = capi.fpAintB_problem(
         a_t.data_ptr(), b_t.data_ptr(), s_t.data_ptr() if s_t is not None else None, c_t.data_ptr(), M, N, K,
         a_dtype=a_dtype, b_dtype=b_dtype, lda=lda, ldb=ldb, ldc=ldc, epilogue=epilogue,
         d0=d0_t.data_ptr() if d0_t is not None else None, d1=d1_t.data_ptr() if d1_t is not None else None,
         k_batch=k_batch, b_layout=b_layout, flags=flags, ldd0=ldd0, ldd1=ldd1, scale_group_k=scale_group_k,
-        ld_scale=ld_scale,
-        c_dtype=(capi.F16 if a_dtype in (capi.F8_FNUZ, capi.F8_E4M3FN) else None))
+        ld_scale=ld_scale, a_block_scale=sa_t.data_ptr() if sa_t is not None else None,
+        b_block_scale=sb_t.data_ptr() if sb_t is not None else None, scale_block=scale_block, ld_a_scale=ld_a_scale,
+        ld_b_scale=ld_b_scale,
+        c_dtype=c_dtype if c_dtype is not None else (capi.F16 if a_dtype in (capi.F8_FNUZ, capi.F8_E4M3FN) else None))
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     if expect_kernel is not None:
         assert capi.kernel_name(p) == expect_kernel, (capi.kernel_name(p), capi.type_string(p))

@@ -254,19 +254,80 @@ def one_case_f8(rng) -> dict:
     return desc
 
 
+def one_case_ab(rng) -> dict:
+    """fp8 x int4 / int8 with block-wise scales of both operands: the dispatcher's kernel (the block-scaled fp8 matrix-core
+    kernel where the block shape allows it) against the general kernel.  Small integers and power-of-two scales keep every
+    block sum, every scaled partial and the running sum exact, so both must give the same bits."""
+    M = int(rng.choice([1, 7, 64, 100, 128, 256, 300, 512, 700, 1024]))
+    N = int(rng.choice([256, 512, 1024, 2048]))
+    K = int(rng.choice([128, 256, 384, 640, 1024, 2048]))
+    fn = bool(rng.integers(0, 2))
+    bf = bool(rng.integers(0, 2))
+    kind = int(rng.integers(0, 3))   # packed int4, pre-shuffled int4, int8
+    bm = int(rng.choice([128, 128, 256, 64]))
+    bn = int(rng.choice([128, 128, 32, 64, 256, 16]))
+    bk = int(rng.choice([128, 128, 128, 64, 256]))
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    if kind == 2:
+        b, b_dtype = dev(q), capi.I8
+    else:
+        b = pack_on_device(q, K, N)
+        b_dtype = capi.I4_PACKED
+        if kind == 1:
+            b, b_dtype = preshuffle(b, True, K, N), capi.I4_PRESHUFFLED
+    lda = K + int(rng.choice([0, 0, 16, 128]))
+    lut = np.zeros(9, dtype=np.uint8)
+    for v, code in (E4M3FN if fn else E4M3FNUZ).items():
+        lut[v + 4] = code
+    a = np.zeros((M, lda), dtype=np.uint8)
+    a[:, :K] = lut[rng.integers(-4, 5, (M, K)) + 4]
+    kblocks = (K + bk - 1) // bk
+    ld_sa = kblocks + int(rng.choice([0, 0, 3]))
+    ld_sb = kblocks + int(rng.choice([0, 0, 5]))
+    sa = (2.0 ** rng.integers(-6, -2, ((M + bm - 1) // bm, ld_sa))).astype(np.float32)
+    sb = (2.0 ** rng.integers(-5, 0, ((N + bn - 1) // bn, ld_sb))).astype(np.float32)
+    kw = dict(a_dtype=capi.F8_E4M3FN if fn else capi.F8_FNUZ, lda=lda, a_block_scale=sa, b_block_scale=sb, scale_block=(bm, bn, bk),
+              ld_a_scale=ld_sa, ld_b_scale=ld_sb, c_dtype=capi.BF16 if bf else capi.F16, b_dtype=b_dtype)
+    if rng.integers(0, 2):
+        kw["ldc"] = N + 8
+    flags = 0 if fn else capi.FLAG_F8_NO_SPECIALS
+    ref = run_fpaintb(a, b, None, M, N, K, flags=capi.FLAG_GENERIC, expect_kernel="wq_gemm_generic", **kw)
+    probe = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, M, N, K, a_dtype=kw["a_dtype"], c_dtype=kw["c_dtype"], b_dtype=b_dtype,
+                                 lda=lda, ldc=kw.get("ldc"), flags=flags, a_block_scale=1 << 20, b_block_scale=1 << 20,
+                                 scale_block=(bm, bn, bk), ld_a_scale=ld_sa, ld_b_scale=ld_sb)
+    if not capi.is_supported(probe):   # (pre-shuffled weights with a block shape only the general kernel takes: refused by design)
+        return {"skipped": capi.lib.wqgemm_last_error().decode()}
+    kernel = capi.kernel_name(probe)
+    want_mfma = kind != 2 and bk == 128 and bm % 128 == 0 and bn % 32 == 0
+    assert (kernel == "wq_gemm_f8_mfma_256_abscale") == want_mfma, (kernel, bm, bn, bk, kind)
+    got = run_fpaintb(a, b, None, M, N, K, flags=flags, **kw)
+    desc = dict(fmt=("i4", "i4pre", "i8")[kind], e4m3fn=fn, bf16=bf, M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), block=[bm, bn, bk],
+                ld_scales=[ld_sa, ld_sb], k_batch=1, kernel=kernel)
+    desc["equal"] = bool(np.array_equal(got[:, :N], ref[:, :N]) and (got[:, :N] != 0x7BFF).any())
+    desc["padding_untouched"] = bool((got[:, N:] == 0x7BFF).all())
+    if not desc["equal"]:
+        bad = got[:, :N] != ref[:, :N]
+        desc["mismatches"] = int(bad.sum())
+        if bad.any():
+            i, j = np.argwhere(bad)[0]
+            desc["first"] = [int(i), int(j), int(got[i, j]), int(ref[i, j])]
+    return desc
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--family", choices=("fp", "i8", "f8"), default="fp",
-                    help="fp: fp16/bf16 x int4/int8; i8: int8 x int8 requantised; f8: fp8 x int4 MultiplyMultiply")
+    ap.add_argument("--family", choices=("fp", "i8", "f8", "ab"), default="fp",
+                    help="fp: fp16/bf16 x int4/int8; i8: int8 x int8 requantised; f8: fp8 x int4 MultiplyMultiply; "
+                         "ab: fp8 x int4/int8 with block-wise scales of both operands")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     kernels, failures, skipped, n = {}, [], 0, 0
     while time.time() - t0 < args.seconds:
-        d = {"fp": one_case, "i8": one_case_i8, "f8": one_case_f8}[args.family](rng)
+        d = {"fp": one_case, "i8": one_case_i8, "f8": one_case_f8, "ab": one_case_ab}[args.family](rng)
         if "skipped" in d:
             skipped += 1
             continue
