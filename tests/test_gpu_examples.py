@@ -143,6 +143,28 @@ def test_reference_profiler_multiply_multiply_loop_dropin(dtype, init, extra):
         assert f"rotating count: {extra[1]}" in r.stdout
 
 
+@pytest.mark.parametrize("dtype,init,extra", [(9, 1, ()), (9, 2, ()), (8, 1, ()), (8, 2, ()), (10, 1, ()), (10, 2, ()), (10, 2, (2, 7, 64))])
+def test_reference_profiler_ab_scale_loop_dropin(dtype, init, extra):
+    """CK's OWN ckProfiler block-scale loop (profile_gemm_ab_scale_impl.hpp, unmodified) instantiated for fp8 activations x
+    ck::int4_t weights with 128 x 128 x 128 scale blocks of both operands: CK generates and uploads operands and scale
+    tensors, runs its host check (operands scaled to fp32, ReferenceGemm, convert) and check_err; the gfx950 operators are
+    found through the factory header this engine adds, pack the weights two per byte and run the block-scaled fp8
+    matrix-core kernel (E4M3FN bytes: one instance; FNUZ bytes: that kernel under the no-special-encodings promise next to
+    the exact general-kernel instance).  (E4M3FN -> bf16, data type 11, is left out: for any A type other than ck::f8_t that
+    loop checks bf16 outputs at check_err's default rtol 1e-3, a fifth of a bf16 rounding step, which only a kernel summing in
+    the host's exact order can meet; for ck::f8_t it uses 5e-2.)"""
+    M, N, K = 512, 768, 1024
+    r = _run(os.path.join(EX, "_ref_build", "ck_profile_gemm_ab_scale_weight_quant_dropin"),
+             "gemm_ab_scale", dtype, 1, 0, 1, init, 0, 1, M, N, K, -1, -1, -1, *extra)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    n_inst = 1 if dtype >= 10 else 2
+    assert f"found {n_inst} instances" in r.stdout and "Best Perf" in r.stdout and "does not support" not in r.stdout
+    assert r.stdout.count("Perf:") == n_inst
+    assert "DeviceGemmMultiD_ABScale_Int4Values_gfx950<" + ("F8_E4M3FN" if dtype >= 10 else "F8_FNUZ") in r.stdout
+    if extra:
+        assert f"rotating count: {extra[1]}" in r.stdout
+
+
 @pytest.mark.parametrize("fmt,gelu,init", [(0, 0, 1), (1, 0, 1), (1, 1, 2), (2, 0, 1), (2, 1, 2)])
 def test_fp8_int4_multiply_multiply_example(fmt, gelu, init):
     """example/65's flow (fp8 A, D0 per column, D1 per row, host ReferenceGemm + check_err): FNUZ bytes through
