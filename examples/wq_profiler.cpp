@@ -3,6 +3,7 @@
 // profiler_operation_registry.hpp:12-70), per-operation argv positions, "Perf:" / "Best Perf ..." lines and
 // host-reference verification taken from
 //   gemm_multiply_multiply   profiler/src/profile_gemm_multiply_multiply.cpp:36-93, .../profile_gemm_multiply_multiply_impl.hpp:131-330
+//   gemm_ab_scale            profiler/src/profile_gemm_ab_scale.cpp:41-182, .../profile_gemm_ab_scale_impl.hpp:39-363
 //   gemm_splitk              profiler/src/profile_gemm_splitk.cpp:34-75, .../profile_gemm_splitk_impl.hpp:101-285
 //   gemm_quantization        the int8 row of profile_gemm.cpp:20-27 with example/14's requantisation epilogue
 // The data-type enums are extended for the weight-quantized forms this engine adds (listed in each usage text).
@@ -420,11 +421,138 @@ int profile_gemm_multiply_multiply(int argc, char* argv[])
     return run_mm<ck::wq_f8_e4m3fn_t, false>(c, sa, sb, se, n_warmup, n_iter, rotating);
 }
 
+// ---- fp8 activations x int4 weights, fp32 scales per 128 x 128 block of both operands ------------------------------------
+template <typename ADataType, typename EDataType, bool NoSpecials>
+int run_ab_scale(const Common& c, ck::index_t sa, ck::index_t sb, ck::index_t se, int n_warmup, int n_iter, uint64_t rotating)
+{
+    constexpr ck::index_t BM = 128, BN = 128, BK = 128;
+    using Op = dev::DeviceGemmMultiD_ABScale_WeightQuant_gfx950<Row, Col, Row, ADataType, ck::wq_int4x2_t, EDataType, BM, BN, BK, NoSpecials>;
+    const auto m = static_cast<std::size_t>(c.M), n = static_cast<std::size_t>(c.N), k = static_cast<std::size_t>(c.K);
+    const std::size_t mb = (m + BM - 1) / BM, nb = (n + BN - 1) / BN, kb = (k + BK - 1) / BK;
+    Tensor<ADataType> a0(HostTensorDescriptor({m, k}, {static_cast<std::size_t>(sa), 1}));
+    Tensor<float> a1(HostTensorDescriptor({mb, kb}, {kb, 1}));
+    Tensor<int8_t> q(HostTensorDescriptor({k, n}, {1, static_cast<std::size_t>(sb)}));
+    Tensor<float> b1(HostTensorDescriptor({kb, nb}, {1, kb}));
+    Tensor<EDataType> e_dev(HostTensorDescriptor({m, n}, {static_cast<std::size_t>(se), 1})), e_host(e_dev.mDesc);
+    std::mt19937 gen(11939);
+    const uint8_t one = std::is_same_v<ADataType, ck::wq_f8_e4m3fn_t> ? 0x38 : 0x40; // 1.0 in E4M3FN / FNUZ
+    auto* bytes       = reinterpret_cast<uint8_t*>(a0.mData.data());
+    for(std::size_t i = 0; i < a0.mData.size(); ++i)
+    {
+        const uint32_t r = gen();
+        if(c.init == 1)
+        {
+            const int v = static_cast<int>(r % 5) - 2; // -2 .. 2, as the reference's GeneratorTensor_2{-2, 2}
+            bytes[i]    = v == 0 ? 0 : static_cast<uint8_t>((v < 0 ? 0x80 : 0) | (one + (std::abs(v) == 2 ? 8 : 0)));
+        }
+        else
+            bytes[i] = static_cast<uint8_t>((r & 0x80) | ((one - 32 + ((r >> 8) % 64)) & 0x7F));
+    }
+    q.GenerateTensorValue(GeneratorTensor_2<int8_t>{-8, 8});
+    a1.GenerateTensorValue(GeneratorTensor_3<float>{0, 1.0}); // (profile_gemm_ab_scale_impl.hpp:104-117)
+    b1.GenerateTensorValue(GeneratorTensor_3<float>{0, 1.0});
+    std::vector<uint8_t> packed(static_cast<std::size_t>(sb) / 2 * n);
+    if(wqgemm_pack_int4_host(q.mData.data(), sb, c.K, c.N, packed.data(), sb / 2) != WQ_OK)
+    {
+        std::cerr << wqgemm_last_error() << std::endl;
+        return 1;
+    }
+    DeviceMem a0_buf(a0.mData.size()), a1_buf(4 * a1.mData.size()), b0_buf(packed.size()), b1_buf(4 * b1.mData.size()),
+        e_buf(sizeof(EDataType) * e_dev.mData.size());
+    a0_buf.ToDevice(a0.mData.data());
+    a1_buf.ToDevice(a1.mData.data());
+    b0_buf.ToDevice(packed.data());
+    b1_buf.ToDevice(b1.mData.data());
+    auto op  = Op{};
+    auto arg = op.MakeArgument(a0_buf.GetDeviceBuffer(), b0_buf.GetDeviceBuffer(), {}, e_buf.GetDeviceBuffer(), c.M, c.N, c.K, sa, sb, {},
+                               se, a1_buf.GetDeviceBuffer(), b1_buf.GetDeviceBuffer(), PassThrough{}, PassThrough{}, PassThrough{});
+    const std::string name = dev::wq_detail::type_string(arg.prob);
+    if(!op.IsSupportedArgument(arg))
+    {
+        std::cout << name << " does not support this problem" << std::endl;
+        return 0;
+    }
+    const int rotating_count = rotating_count_for(rotating, a0.mData.size() + packed.size() + 4 * (a1.mData.size() + b1.mData.size()), n_iter);
+    std::cout << "rotating count: " << rotating_count << std::endl;
+    const float ms = op.MakeInvoker().Run(arg, stream_config(c.time, n_warmup, n_iter, rotating_count));
+    hip_check_error(hipDeviceSynchronize());
+    bool pass = true;
+    if(c.verify)
+    {
+        // the reference's host check (profile_gemm_ab_scale_impl.hpp:165-213): both operands scaled to fp32, ReferenceGemm, convert
+        e_buf.FromDevice(e_dev.mData.data());
+        Tensor<float> a_f(HostTensorDescriptor({m, k}, {k, 1})), b_f(HostTensorDescriptor({k, n}, {1, k})), acc(HostTensorDescriptor({m, n}, {n, 1}));
+        for(std::size_t i = 0; i < m; ++i)
+            for(std::size_t kk = 0; kk < k; ++kk)
+                a_f(i, kk) = ck::type_convert<float>(a0(i, kk)) * a1(i / BM, kk / BK);
+        for(std::size_t j = 0; j < n; ++j)
+            for(std::size_t kk = 0; kk < k; ++kk)
+                b_f(kk, j) = static_cast<float>(q(kk, j)) * b1(kk / BK, j / BN);
+        using Ref = ck::tensor_operation::host::ReferenceGemm<float, float, float, float, PassThrough, PassThrough, PassThrough>;
+        auto ref  = Ref{};
+        ref.MakeInvoker().Run(ref.MakeArgument(a_f, b_f, acc, PassThrough{}, PassThrough{}, PassThrough{}));
+        for(std::size_t i = 0; i < m; ++i)
+            for(std::size_t j = 0; j < n; ++j)
+                e_host(i, j) = ck::type_convert<EDataType>(acc(i, j));
+        pass = ck::utils::check_err(e_dev, e_host, "Error: Incorrect results!", 5e-2, 5e-2); // (:263-271, the fp8 tolerances)
+        std::cout << (pass ? "verification: PASS" : "verification: FAIL") << std::endl;
+    }
+    if(c.time)
+        report(std::is_same_v<EDataType, ck::bhalf_t> ? "bf16" : "f16", c.M, c.N, c.K, sa, sb, se, ms,
+               m * k + k * n / 2 + sizeof(EDataType) * m * n, name);
+    return pass ? 0 : 1;
+}
+
+// argv positions of profiler/src/profile_gemm_ab_scale.cpp:41-95: the scale-block-tile selector sits at arg4, everything after
+// it one position later than in the other operations
+int profile_gemm_ab_scale(int argc, char* argv[])
+{
+    Common c{};
+    bool ok = argc == 15 || argc == 18;
+    if(ok)
+    {
+        c.data_type = std::stoi(argv[2]);
+        c.layout    = std::stoi(argv[3]);
+        c.verify    = std::stoi(argv[5]);
+        c.init      = std::stoi(argv[6]);
+        c.log       = std::stoi(argv[7]);
+        c.time      = std::stoi(argv[8]);
+        c.M = std::stoi(argv[9]), c.N = std::stoi(argv[10]), c.K = std::stoi(argv[11]);
+        ok = c.layout == 1 && std::stoi(argv[4]) == 0 && c.data_type >= 8 && c.data_type <= 11;
+    }
+    if(!ok)
+    {
+        std::cout << "arg1: tensor operation (gemm_ab_scale: GEMM_AB_Scale)\n"
+                  << "arg2: data type (8: f8 FNUZ@int4 -> f16, no 0x7F/0xFF/0x80 bytes; 9: the same -> bf16; 10: f8 E4M3FN@int4 -> f16; "
+                     "11: -> bf16)\n"
+                  << "arg3: matrix layout (1: A[m, k] * B[n, k] = C[m, n])\n"
+                  << "arg4: scale block tile (0: ScaleBlockM/N/K = [128, 128, 128])\n"
+                  << "arg5: verification (0: no; 1: yes)\narg6: initialization (0: no init; 1: integer value; 2: decimal value)\n"
+                  << "arg7: print tensor value (0: no; 1: yes)\narg8: time kernel (0=no, 1=yes)\n"
+                  << "arg9 to 14: M, N, K, StrideA, StrideB, StrideE\noptional:\n"
+                  << "arg15: number of warm-up cycles (default 1)\narg16: number of iterations (default 10)\n"
+                  << "arg17: memory for rotating buffer (default 0, size in MB)\n";
+        return 1;
+    }
+    auto stride = [](int v, int dflt) { return v < 0 ? dflt : v; };
+    const int sa = stride(std::stoi(argv[12]), c.K), sb = stride(std::stoi(argv[13]), c.K), se = stride(std::stoi(argv[14]), c.N);
+    const int n_warmup = argc == 18 ? std::stoi(argv[15]) : 1, n_iter = argc == 18 ? std::stoi(argv[16]) : 10;
+    const uint64_t rotating = argc == 18 ? std::stoull(argv[17]) * 1024 * 1024 : 0;
+    switch(c.data_type)
+    {
+    case 8: return run_ab_scale<ck::f8_t, ck::half_t, true>(c, sa, sb, se, n_warmup, n_iter, rotating);
+    case 9: return run_ab_scale<ck::f8_t, ck::bhalf_t, true>(c, sa, sb, se, n_warmup, n_iter, rotating);
+    case 10: return run_ab_scale<ck::wq_f8_e4m3fn_t, ck::half_t, false>(c, sa, sb, se, n_warmup, n_iter, rotating);
+    default: return run_ab_scale<ck::wq_f8_e4m3fn_t, ck::bhalf_t, false>(c, sa, sb, se, n_warmup, n_iter, rotating);
+    }
+}
+
 const Register r0("gemm_fpAintB", "GEMM with weight-only quantized B (fp16 / bf16 x int4 / int8)", profile_gemm_fpaintb);
 const Register r1("gemm_splitk", "Split-K GEMM with weight-only quantized B", profile_gemm_splitk);
 const Register r2("gemm_quantization", "int8 GEMM + Activation_Mul_Clamp", profile_gemm_quantization);
 const Register r2g("gemm", "GEMM (data type 3: int8, requantised)", profile_gemm_quantization);
 const Register r3("gemm_multiply_multiply", "GEMM_Multiply_Multiply (fp8 x int4)", profile_gemm_multiply_multiply);
+const Register r4("gemm_ab_scale", "GEMM_AB_Scale (fp8 x int4, 128 x 128 x 128 block scales of both operands)", profile_gemm_ab_scale);
 
 } // namespace
 

@@ -186,6 +186,23 @@ def test_fp8_int4_ab_scale_example(fmt, init):
     assert "16x16x128_f8f6f4" in r.stdout, r.stdout
 
 
+@pytest.mark.parametrize("args", [
+    ("gemm_ab_scale", 9, 1, 0, 1, 2, 0, 1, 640, 512, 1024, -1, -1, -1),
+    ("gemm_ab_scale", 8, 1, 0, 1, 1, 0, 1, 256, 256, 384, -1, -1, -1),
+    ("gemm_ab_scale", 10, 1, 0, 1, 2, 0, 1, 512, 768, 512, -1, -1, -1),
+    ("gemm_ab_scale", 11, 1, 0, 1, 1, 0, 1, 300, 256, 256, -1, -1, -1, 2, 7, 16),
+])
+def test_profiler_cli_ab_scale(args):
+    """The gemm_ab_scale operation of the ckProfiler-style command line (argv positions of profile_gemm_ab_scale.cpp: the
+    scale-block-tile selector at arg4), verified by the reference's host check at its fp8 tolerances."""
+    r = _run(os.path.join(EX, "example_wq_profiler"), *args)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verification: PASS" in r.stdout and "Best Perf for datatype" in r.stdout
+    assert "ABScalePer128K" in r.stdout
+    if len(args) == 17:
+        assert "rotating count: 7" in r.stdout
+
+
 def test_reference_client_example09_source_dropin():
     """CK's client_example/09_quantization/gemm_quantization.cpp, compiled unmodified, must find the gfx950
     operator through CK's own DeviceOperationInstanceFactory (the add_device_* symbols come from
