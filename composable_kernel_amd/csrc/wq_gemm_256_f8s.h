@@ -61,7 +61,7 @@ struct Mfma256F8S
 //   4096 cycle stamps (s_memtime) at entry, first row block, end of the K loop and exit -> p.dbg[workgroup][wave][4]
 // ABSCALE: block-wise scales of both operands (GemmParams::sa / sb; one K tile = one 128-k scale block).  Every row block's
 // MFMAs then start from zero and their sums are folded into the accumulators with the block's a_scale * b_scale (one fused
-// multiply-add per accumulator register and K tile); the scales of the workgroup's two 128-row halves and of each wave's
+// multiply-add per accumulator register and K tile, issued one row block after the MFMAs so that it never waits for them); the scales of the workgroup's two 128-row halves and of each wave's
 // 32 columns sit in two small LDS tables behind the C tile image, written in the prologue.
 template <int PROBE, bool ABSCALE = false>
 __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
@@ -203,6 +203,7 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
     [[maybe_unused]] const float* tab_a = (const float*)(lds + T::TAB_A);
     [[maybe_unused]] const float* tab_b = (const float*)(lds + T::TAB_B) + wave * T::TAB_LD;
     [[maybe_unused]] float s_lo = 0.f, s_hi = 0.f, s_lo_next = 0.f, s_hi_next = 0.f; // a_scale * b_scale of rows 0..127 / 128..255
+    [[maybe_unused]] f4_t pend0 = {0.f, 0.f, 0.f, 0.f}, pend1 = {0.f, 0.f, 0.f, 0.f}; // block sums of the previous row block, not yet folded in
     if constexpr(ABSCALE)
     {
         // FNUZ bytes are multiplied as twice their value: their 2^-1 rides on the activation scales
@@ -352,6 +353,16 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
             }
             if constexpr(ABSCALE)
             {
+                // The block sums of row block mt - 1 are folded in now, a row block after their MFMAs were issued, so that the fused
+                // multiply-adds do not wait for a result (the last row block of a tile folds its own: nothing crosses the tile boundary).
+                if constexpr(mt > 0)
+                {
+                    constexpr int pm = mt - 1;
+                    const float ps   = pm < MT / 2 ? s_lo : s_hi;
+                    const f4_t sv    = {ps, ps, ps, ps};
+                    acc[0][pm]       = __builtin_elementwise_fma(pend0, sv, acc[0][pm]);
+                    acc[1][pm]       = __builtin_elementwise_fma(pend1, sv, acc[1][pm]);
+                }
                 if constexpr(mt == 0)
                     s_lo = s_lo_next, s_hi = s_hi_next;
                 if constexpr(mt == MT / 2)
@@ -361,12 +372,24 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                     s_lo_next = tab_a[2 * (t + 1)] * sbn, s_hi_next = tab_a[2 * (t + 1) + 1] * sbn;
                 }
                 const f4_t zero = {0.f, 0.f, 0.f, 0.f};
-                const f4_t t0   = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], zero, 1, 0, 0, 0, 0, 0);
-                const f4_t t1   = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], zero, 1, 0, 0, 0, 0, 0);
-                const float s   = mt < MT / 2 ? s_lo : s_hi;
-                const f4_t sv   = {s, s, s, s};
-                acc[0][mt]      = __builtin_elementwise_fma(t0, sv, acc[0][mt]);
-                acc[1][mt]      = __builtin_elementwise_fma(t1, sv, acc[1][mt]);
+                pend0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], zero, 1, 0, 0, 0, 0, 0);
+                pend1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], zero, 1, 0, 0, 0, 0, 0);
+                if constexpr(!(PROBE & 1))
+                    convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
+                if constexpr(mt == MT - 1) // (nothing is carried across the tile boundary)
+                {
+                    const f4_t sv = {s_hi, s_hi, s_hi, s_hi};
+                    acc[0][mt]    = __builtin_elementwise_fma(pend0, sv, acc[0][mt]);
+                    acc[1][mt]    = __builtin_elementwise_fma(pend1, sv, acc[1][mt]);
+                }
+                // (the four pending fused multiply-adds behind the fragment reads, the conversion behind the MFMAs)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             else if constexpr(!(PROBE & 16))
             {
@@ -390,17 +413,11 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                 asm volatile("" ::"v"(wf[P][0]), "v"(wf[P][1]), "v"(af[w]));
             }
             // weights of tile t+1: half a piece (4 weights) per row block, its VALU work behind the two MFMAs
-            if constexpr(!(PROBE & 1))
+            if constexpr(!(PROBE & 1) && !ABSCALE)
                 convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
             constexpr int ORDER = (PROBE >> 7) & 3; // (diagnostic: other placements of the conversion work)
             if constexpr(ABSCALE)
             {
-                // (the conversion behind the first MFMA, the fused multiply-adds of both sums behind the second)
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
             else if constexpr(ORDER == 0)
             {
