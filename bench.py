@@ -480,15 +480,30 @@ def run_splitk(args):
     if args.exchange == "torch":
         exchange = "torch_distributed"
     else:
+        # Every rank takes part in the broadcast whatever happens before it (a rank that raised ahead of a collective
+        # would leave the others waiting in it): rank 0 sends zeros when it could not make an id, and nobody then
+        # calls ncclCommInitRank.
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        rccl = None
         try:
             from composable_kernel_amd import rccl
-            uid = torch.zeros(rccl.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+            assert rccl.UNIQUE_ID_BYTES == uid.numel()
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(rccl.get_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, src=0)
-            comm = rccl.comm_init_rank(world, bytes(uid.cpu().numpy().tobytes()), rank)
         except Exception as exc:  # noqa: BLE001  (reported in the JSON line; the torch.distributed form then runs)
-            exchange, comm_error = "torch_distributed", f"{type(exc).__name__}: {exc}"
+            exchange, comm_error, rccl = "torch_distributed", f"{type(exc).__name__}: {exc}", None
+            uid.zero_()
+        dist.broadcast(uid, src=0)
+        have_id = bool(uid.any().item())
+        can = torch.tensor([1 if (rccl is not None and have_id) else 0], device=dev)
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)  # (ncclCommInitRank is itself collective: all ranks or none)
+        if int(can.item()) == 1:
+            try:
+                comm = rccl.comm_init_rank(world, bytes(uid.cpu().numpy().tobytes()), rank)
+            except Exception as exc:  # noqa: BLE001
+                exchange, comm_error = "torch_distributed", f"{type(exc).__name__}: {exc}"
+        elif exchange == "c_abi_rccl":
+            exchange, comm_error = "torch_distributed", comm_error or "another rank could not load RCCL's C API"
     ok_all = torch.tensor([1 if comm is not None else 0], device=dev)
     dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
     if int(ok_all.item()) == 0 and exchange == "c_abi_rccl":
