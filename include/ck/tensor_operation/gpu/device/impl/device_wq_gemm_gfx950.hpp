@@ -223,10 +223,13 @@ inline std::string type_string(const wqgemm_problem& prob)
 
 // Device memory for the arguments' own scratch, recycled: an Argument takes a block when it is made and hands it back when
 // its last copy goes, so a caller that makes arguments in a loop (the profilers do, once per instance and problem) meets
-// hipMalloc -- a call that synchronises the device -- only until the pool holds a block that fits.  Every Argument still
-// has a block of its own while it lives (arguments used at the same time on different streams never share scratch).
-// Blocks are kept per device, at most kMaxIdle of them and kMaxIdleBytes in all; what exceeds that is freed at once.  The
-// pool itself is never destroyed (at process exit the HIP runtime may be gone before static destructors run).
+// hipMalloc only until the pool holds a block that fits.  Every Argument still has a block of its own while it lives
+// (arguments used at the same time on different streams never share scratch).  A block that comes back may still be read
+// or written by launches in flight on any stream -- the pool does not know which -- so a block is handed out again only
+// behind a hipDeviceSynchronize of its device (microseconds on an idle device, and no more of a synchronisation than the
+// hipMalloc it replaces).  Blocks are kept per device, at most kMaxIdle of them and kMaxIdleBytes in all; what exceeds that
+// is freed at once.  The pool itself is never destroyed (at process exit the HIP runtime may be gone before static
+// destructors run).
 class ScratchPool
 {
     public:
@@ -240,7 +243,7 @@ class ScratchPool
         int dev = 0;
         if(hipGetDevice(&dev) != hipSuccess)
             return nullptr;
-        Block blk{nullptr, 0, dev, nullptr};
+        Block blk{nullptr, 0, dev};
         {
             std::lock_guard<std::mutex> lock(mu_);
             // the smallest idle block of this device that fits and is not more than twice as large
@@ -256,14 +259,13 @@ class ScratchPool
                 idle_.erase(idle_.begin() + best);
             }
         }
-        if(blk.ptr && blk.idle_since)
+        if(blk.ptr)
         {
-            // launches that used the block were enqueued before it came back: wait for them (normally long done)
-            (void)hipEventSynchronize(blk.idle_since);
-            (void)hipEventDestroy(blk.idle_since);
-            blk.idle_since = nullptr;
+            // whatever used the block before it came back has to be done before its next owner writes to it
+            if(hipDeviceSynchronize() != hipSuccess)
+                (void)hipGetLastError();
         }
-        if(!blk.ptr)
+        else
         {
             if(hipMalloc(&blk.ptr, bytes) != hipSuccess)
             {
@@ -281,7 +283,6 @@ class ScratchPool
         void* ptr;
         size_t bytes;
         int dev;
-        hipEvent_t idle_since; // recorded on the default stream when the block came back (orders after work on blocking streams)
     };
     static constexpr size_t kMaxIdle = 8, kMaxIdleBytes = size_t(2) << 30;
     void give(Block blk)
@@ -290,21 +291,6 @@ class ScratchPool
             std::lock_guard<std::mutex> lock(mu_);
             if(idle_.size() < kMaxIdle && idle_bytes_ + blk.bytes <= kMaxIdleBytes)
             {
-                int cur = 0;
-                if(hipGetDevice(&cur) == hipSuccess && cur == blk.dev && hipEventCreateWithFlags(&blk.idle_since, hipEventDisableTiming) == hipSuccess)
-                {
-                    if(hipEventRecord(blk.idle_since, nullptr) != hipSuccess)
-                    {
-                        (void)hipEventDestroy(blk.idle_since);
-                        blk.idle_since = nullptr;
-                        (void)hipDeviceSynchronize();
-                    }
-                }
-                else
-                {
-                    blk.idle_since = nullptr;
-                    (void)hipGetLastError();
-                }
                 idle_.push_back(blk);
                 idle_bytes_ += blk.bytes;
                 return;
