@@ -290,8 +290,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         if(p->ld_a_scale < 0 || p->ld_b_scale < 0 || (p->ld_a_scale != 0 && p->ld_a_scale < kblocks) ||
            (p->ld_b_scale != 0 && p->ld_b_scale < kblocks))
             return fail(WQ_ERR_INVALID, "ld_a_scale / ld_b_scale must be 0 or at least ceil(K / scale_block_k) = %d", kblocks);
-        if(plan.partial)
-            return fail(WQ_ERR_UNSUPPORTED, "block-wise scales are not combined with k_batch or K slices");
+        // (K slices and k_batch: every kernel indexes the scale tables with the absolute k, and the fp32 partials already
+        // carry the scales, so the slabs sum like any others)
         if((uintptr_t)p->a_block_scale % 4 != 0 || (uintptr_t)p->b_block_scale % 4 != 0)
             return fail(WQ_ERR_INVALID, "block scales are fp32: 4-byte aligned pointers");
     }
@@ -443,7 +443,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         // 8 bytes per slice and output at 8 TB/s (they mostly stay in the last-level cache) plus 3 us for the reduction.
         const int tiles = ((p->M + 255) / 256) * (p->N / 256);
         const int klen  = plan.k_end - plan.k_begin;
-        if(!plan.partial && tiles < 256 && !ab_scaled)
+        if(!plan.partial && tiles < 256)
         {
             double best = 1e30;
             int kb      = 1;

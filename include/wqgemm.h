@@ -155,7 +155,8 @@ typedef struct wqgemm_problem
      * (scale_block_k = 128, scale_block_m a multiple of 128, scale_block_n a multiple of 32, no more than 640 K tiles)
      * sums each 128-k block exactly on the matrix core and applies a_scale * b_scale to the block's sum: the same value up
      * to fp32 rounding (identical when the scales are powers of two).  ld_a_scale >= ceil(K / scale_block_k),
-     * ld_b_scale >= ceil(K / scale_block_k); 0 = exactly that.  Not combined with k_batch / K slices. */
+     * ld_b_scale >= ceil(K / scale_block_k); 0 = exactly that.  k_batch and K slices (k_begin / k_end) combine with it: the tables
+     * are indexed with the absolute k, and the fp32 partials carry the scales. */
     const void* a_block_scale;
     const void* b_block_scale;
     int32_t scale_block_m, scale_block_n, scale_block_k;

@@ -20,7 +20,7 @@ AB = "wq_gemm_f8_mfma_256_abscale"
 
 
 def run(a, b_t, sa, sb, M, N, K, block, ld_sa, ld_sb, *, bf16, b_dtype, a_dtype=capi.F8_FNUZ, flags=0, expect=None,
-        epilogue=capi.EPI_PASSTHROUGH, d0=None, d1=None, ldb=None):
+        epilogue=capi.EPI_PASSTHROUGH, d0=None, d1=None, ldb=None, k_batch=1, workspace=True):
     a_t, sa_t, sb_t = dev(a), dev(np.ascontiguousarray(sa, np.float32)), dev(np.ascontiguousarray(sb, np.float32))
     c_t = torch.full((M + 16, N), 0x7BFF, dtype=torch.int16, device="cuda")
     keep = [dev(d0) if d0 is not None else None, dev(d1) if d1 is not None else None]
@@ -28,12 +28,13 @@ def run(a, b_t, sa, sb, M, N, K, block, ld_sa, ld_sb, *, bf16, b_dtype, a_dtype=
                              c_dtype=capi.BF16 if bf16 else capi.F16, flags=flags, a_block_scale=sa_t.data_ptr(),
                              b_block_scale=sb_t.data_ptr(), scale_block=block, ld_a_scale=ld_sa, ld_b_scale=ld_sb, epilogue=epilogue,
                              d0=keep[0].data_ptr() if keep[0] is not None else None,
-                             d1=keep[1].data_ptr() if keep[1] is not None else None, ldb=ldb)
+                             d1=keep[1].data_ptr() if keep[1] is not None else None, ldb=ldb, k_batch=k_batch)
     assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
     if expect:
-        assert capi.kernel_name(p) == expect, capi.kernel_name(p)
-    assert capi.workspace_bytes(p) == 0
-    capi.launch(p, None, torch.cuda.current_stream().cuda_stream)
+        assert capi.kernel_name(p).startswith(expect), capi.kernel_name(p)
+    nbytes = capi.workspace_bytes(p)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if nbytes and workspace else None
+    capi.launch(p, ws.data_ptr() if ws is not None else None, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     out = host_u16(c_t)
     assert (out[M:] == 0x7BFF).all()
@@ -131,7 +132,6 @@ def test_block_scales_with_an_epilogue_and_refusals(port):
     assert capi.is_supported(prob())
     assert not capi.is_supported(prob(b_block_scale=None))
     assert b"pairs" in capi.lib.wqgemm_last_error()
-    assert not capi.is_supported(prob(k_batch=2))
     assert not capi.is_supported(prob(scale_block=(128, 128, 0)))
     assert not capi.is_supported(prob(ld_a_scale=1))
     half = dev(np.zeros((M, K), np.uint16))
@@ -141,3 +141,46 @@ def test_block_scales_with_an_epilogue_and_refusals(port):
     # block sizes the matrix-core kernel does not take run on the general kernel
     assert capi.kernel_name(prob(scale_block=(64, 128, 128))) == "wq_gemm_generic"
     assert capi.kernel_name(prob(scale_block=(128, 128, 64))) == "wq_gemm_generic"
+
+
+@pytest.mark.parametrize("M,N,K,kb,fn", [(512, 512, 2048, 2, True), (256, 256, 1536, 3, False), (300, 512, 1024, 4, True)])
+def test_block_scales_with_split_k(M, N, K, kb, fn):
+    """k_batch slices of a block-scaled problem: the scale tables are indexed with the absolute k and the fp32 partials carry
+    the scales, so on data whose partial sums are exact (small integers, power-of-two scales) the split result equals the
+    single pass bit for bit -- on the matrix-core kernel and on the general kernel."""
+    rng = np.random.default_rng(K + kb)
+    block = (128, 128, 128)
+    one = 0x38 if fn else 0x40
+    lut = np.array([0x80 | (one + 8), 0x80 | one, 0, one, one + 8], np.uint8)
+    a = lut[rng.integers(0, 5, (M, K))]
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    kblocks = K // 128
+    sa = np.exp2(rng.integers(-4, 0, ((M + 127) // 128, kblocks))).astype(np.float32)
+    sb = np.exp2(rng.integers(-4, 0, (N // 128, kblocks))).astype(np.float32)
+    bp = pack_on_device(q, K, N)
+    kw = dict(bf16=False, b_dtype=capi.I4_PACKED, a_dtype=capi.F8_E4M3FN if fn else capi.F8_FNUZ)
+    flags = 0 if fn else capi.FLAG_F8_NO_SPECIALS
+    single = run(a, bp, sa, sb, M, N, K, block, kblocks, kblocks, flags=flags, expect=AB, **kw)
+    split = run(a, bp, sa, sb, M, N, K, block, kblocks, kblocks, flags=flags, expect=AB, k_batch=kb, **kw)
+    np.testing.assert_array_equal(split, single)
+    gen = run(a, bp, sa, sb, M, N, K, block, kblocks, kblocks, flags=capi.FLAG_GENERIC, expect="wq_gemm_generic", k_batch=kb, **kw)
+    np.testing.assert_array_equal(gen, single)
+
+
+def test_block_scales_planner_split_for_a_short_grid():
+    """A grid far shorter than the chip (64 rows against 1024 columns, K = 4096) gets the planner's own K split when a
+    workspace is there (kernel name with the reduce stage), one slice without it; same bits either way on exact data."""
+    rng = np.random.default_rng(5)
+    M, N, K, block = 64, 1024, 4096, (128, 128, 128)
+    lut = np.array([0xC0, 0xB8, 0, 0x38, 0x40], np.uint8)
+    a = lut[rng.integers(0, 5, (M, K))]
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    sa = np.exp2(rng.integers(-4, 0, (1, K // 128))).astype(np.float32)
+    sb = np.exp2(rng.integers(-4, 0, (N // 128, K // 128))).astype(np.float32)
+    bp = pack_on_device(q, K, N)
+    kw = dict(bf16=True, b_dtype=capi.I4_PACKED, a_dtype=capi.F8_E4M3FN)
+    with_ws = run(a, bp, sa, sb, M, N, K, block, 0, 0, expect=AB, **kw)
+    without = run(a, bp, sa, sb, M, N, K, block, 0, 0, expect=AB, workspace=False, **kw)
+    np.testing.assert_array_equal(with_ws, without)
+    gen = run(a, bp, sa, sb, M, N, K, block, 0, 0, flags=capi.FLAG_GENERIC, expect="wq_gemm_generic", **kw)
+    np.testing.assert_array_equal(with_ws, gen)
