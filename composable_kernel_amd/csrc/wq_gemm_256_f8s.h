@@ -62,10 +62,17 @@ struct Mfma256F8S
 // ABSCALE: block-wise scales of both operands (GemmParams::sa / sb; one K tile = one 128-k scale block).  Every row block's
 // MFMAs then start from zero and their sums are folded into the accumulators with the block's a_scale * b_scale (one fused
 // multiply-add per accumulator register and K tile, issued one row block after the MFMAs so that it never waits for them); the scales of the workgroup's two 128-row halves and of each wave's
-// 32 columns sit in two small LDS tables behind the C tile image, written in the prologue.
-template <int PROBE, bool ABSCALE = false>
+// 32 columns sit in two small LDS tables behind the C tile image, written in the prologue.  With finer activation blocks
+// (ABSCALE = 2: per-token scales and the like) the scales of the tile's 256 rows for one K tile travel with that tile instead:
+// one more LDS-DMA piece (4 bytes per lane, rows 64 (w & 3) .. + 63 by wave w; waves w and w + 4 write the same bytes) into a
+// ring of four 1 KiB slots, and every row block reads its lane's row scale from there.
+template <int PROBE, int ABSCALE = 0>
 __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 {
+    // ABSCALE: 0 none, 1 one activation scale per 128-row half of the tile (scale_block_m a multiple of 128), 2 one per row
+    // (any other scale_block_m: row r takes table row (m0 + r) / scale_block_m)
+    constexpr bool ROWSCALE = ABSCALE == 2;
+    constexpr int AD        = Mfma256F8S::A_DMA + (ROWSCALE ? 1 : 0); // LDS-DMA instructions per wave and tile
     using T = Mfma256F8S;
     constexpr int MT = 16, NT = 2, LEAD = T::LEAD, WIN = LEAD + 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -200,6 +207,25 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
         return;
     }
 
+    // Row-scale form: the activation scales of K tile `tile` for rows 64 (wave & 3) + lane, one float per lane, by LDS-DMA
+    // into slot `slot` of a four-slot ring at TAB_A (rows past M re-read row M - 1: never stored)
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t s_rsrc = null_rsrc;
+    [[maybe_unused]] uint32_t s_lane = 0, s_run = 0;
+    if constexpr(ROWSCALE)
+    {
+        s_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.sa, 0, 0x7FFFFFFF, 0x00020000);
+        s_lane = (uint32_t)(min(m0 + 64 * (wave & 3) + lane, p.M - 1) / p.bm) * (uint32_t)p.ld_sa * 4u;
+        s_run  = (uint32_t)(kz_begin / T::BK) * 4u;
+    }
+    auto dma_s = [&](const __amdgpu_buffer_rsrc_t& rsrc, int slot) __attribute__((always_inline)) {
+        if constexpr(ROWSCALE)
+        {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + T::TAB_A + slot * 1024 + (wave & 3) * 256),
+                                                     4, s_lane, s_run, 0, 0);
+            s_run += 4;
+        }
+    };
+
     [[maybe_unused]] const float* tab_a = (const float*)(lds + T::TAB_A);
     [[maybe_unused]] const float* tab_b = (const float*)(lds + T::TAB_B) + wave * T::TAB_LD;
     [[maybe_unused]] float s_lo = 0.f, s_hi = 0.f, s_lo_next = 0.f, s_hi_next = 0.f; // a_scale * b_scale of rows 0..127 / 128..255
@@ -211,16 +237,19 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
         const int kt0    = kz_begin / T::BK;
         float* wa        = (float*)(lds + T::TAB_A);
         float* wb        = (float*)(lds + T::TAB_B);
-        for(int i = threadIdx.x; i < 2 * (ntiles + 1); i += T::THREADS)
-        {
-            const int tt = min(i >> 1, ntiles - 1), h = i & 1;
-            const int mb = min(m0 + h * 128, p.M - 1) / p.bm;
-            wa[i]        = p.sa[(size_t)mb * p.ld_sa + kt0 + tt] * half;
-        }
+        if constexpr(!ROWSCALE)
+            for(int i = threadIdx.x; i < 2 * (ntiles + 1); i += T::THREADS)
+            {
+                const int tt = min(i >> 1, ntiles - 1), h = i & 1;
+                const int mb = min(m0 + h * 128, p.M - 1) / p.bm;
+                wa[i]        = p.sa[(size_t)mb * p.ld_sa + kt0 + tt] * half;
+            }
         for(int i = threadIdx.x; i < 8 * (ntiles + 1); i += T::THREADS)
         {
             const int wv = i / (ntiles + 1), tt = min(i % (ntiles + 1), ntiles - 1);
-            wb[wv * T::TAB_LD + i % (ntiles + 1)] = p.sb[(size_t)(kt0 + tt) + (size_t)((n0 + wv * 32) / p.bn) * p.ld_sb];
+            // (row-scale form: the activations' 2^-1 rides on the weight scales)
+            wb[wv * T::TAB_LD + i % (ntiles + 1)] =
+                p.sb[(size_t)(kt0 + tt) + (size_t)((n0 + wv * 32) / p.bn) * p.ld_sb] * (ROWSCALE ? half : 1.f);
         }
         // (visible to every wave behind the prologue's barrier below)
     }
@@ -230,10 +259,12 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 #pragma unroll
     for(int i = 0; i < T::A_DMA; ++i)
         dma_a(a_rsrc, 0, i);
+    dma_s(s_rsrc, 0);
     load_b(b_rsrc, raw[0], 0);
     {
         const __amdgpu_buffer_rsrc_t a1 = ntiles > 1 ? a_rsrc : null_rsrc, b1 = ntiles > 1 ? b_rsrc : null_rsrc;
         const __amdgpu_buffer_rsrc_t a2 = ntiles > 2 ? a_rsrc : null_rsrc;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t s1 = ntiles > 1 ? s_rsrc : null_rsrc, s2 = ntiles > 2 ? s_rsrc : null_rsrc;
         if constexpr(SPREAD)
         {
             // (the weights first: tile 0 waits for them with the loop's own count, which needs four operations behind them)
@@ -248,16 +279,22 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 #pragma unroll
             for(int i = 0; i < T::A_DMA; ++i)
                 dma_a(a1, 1, i);
+            dma_s(s1, 1);
+            if constexpr(ROWSCALE)
+                __builtin_amdgcn_sched_barrier(0); // (issue order is part of the vmcnt arithmetic)
             load_b(b1, raw[1], 1);
+            if constexpr(ROWSCALE)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for(int i = 0; i < T::A_DMA; ++i)
                 dma_a(a2, 2, i);
+            dma_s(s2, 2);
         }
     }
     // (everything the first loads do not need happens while they are in flight: the 128 accumulator registers are cleared here)
     __builtin_amdgcn_sched_barrier(0);
     clear_acc();
-    wait_vmcnt<SPREAD ? T::A_DMA + 3 : 2 * T::A_DMA + 2>(); // A(0), B(0) done
+    wait_vmcnt<SPREAD ? T::A_DMA + 3 : 2 * AD + 2>(); // A(0), B(0) done
     __builtin_amdgcn_s_barrier();
     {
         convert_piece(wf[0], raw[0], std::integral_constant<int, 0>{});
@@ -269,7 +306,9 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
         convert_piece(wf[0], raw[0], std::integral_constant<int, 6>{});
         convert_piece(wf[0], raw[0], std::integral_constant<int, 7>{});
     }
-    if constexpr(ABSCALE)
+    if constexpr(ROWSCALE)
+        s_lo_next = tab_b[0]; // (s_lo = the wave's weight scale of the tile; the row scale comes from the ring)
+    else if constexpr(ABSCALE)
     {
         const float sb0 = tab_b[0];
         s_lo_next = tab_a[0] * sb0, s_hi_next = tab_a[1] * sb0;
@@ -294,6 +333,8 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
         const __amdgpu_buffer_rsrc_t b2 = t + 2 < ntiles ? b_rsrc : null_rsrc;
         const __amdgpu_buffer_rsrc_t a2 = t + 2 < ntiles ? a_rsrc : null_rsrc;
         const __amdgpu_buffer_rsrc_t a3 = t + 3 < ntiles ? a_rsrc : null_rsrc;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t s3 = t + 3 < ntiles ? s_rsrc : null_rsrc;
+        [[maybe_unused]] const float* row_s = (const float*)(lds + T::TAB_A + slot * 1024) + fr; // row 16 mt + fr at [16 mt]
 
         auto row_block = [&](auto mt_c) __attribute__((always_inline)) {
             constexpr int mt = decltype(mt_c)::value;
@@ -305,7 +346,7 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                 // (behind the last piece of A(t+1) -- SPREAD: issued in row block 9 of tile t-1 -- came A(t+2) piece 0, B(t+2) x 2
                 // and A(t+2) pieces 1 .. 3)
                 if constexpr(!(PROBE & 4))
-                    wait_vmcnt<SPREAD ? 6 : T::A_DMA + 4>();
+                    wait_vmcnt<SPREAD ? 6 : AD + 4>();
                 if constexpr(!(PROBE & 8))
                     __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -329,7 +370,7 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
             if constexpr(!(PROBE & 4))
             {
                 if constexpr(mt == 0)
-                    wait_vmcnt<T::A_DMA>(); // B(t+1) has landed (issued a tile ago); behind it: A(t+2) x 4
+                    wait_vmcnt<AD>(); // B(t+1) has landed (issued a tile ago); behind it: A(t+2) x 4 (and its row scales)
                 if constexpr(mt == 0 && !(PROBE & 2048))
                     load_b(b2, raw[P], t + 2); // B(t+2): raw[P] held tile t's weights, converted during tile t-1
                 if constexpr(PROBE & 1024)
@@ -348,7 +389,10 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                 {
                     dma_a(a3, slot3, mt - (MT - LEAD));
                     if constexpr(mt == MT - 1)
+                    {
                         dma_a(a3, slot3, T::A_DMA - 1);
+                        dma_s(s3, slot3);
+                    }
                 }
             }
             if constexpr(ABSCALE)
@@ -358,18 +402,23 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                 if constexpr(mt > 0)
                 {
                     constexpr int pm = mt - 1;
-                    const float ps   = pm < MT / 2 ? s_lo : s_hi;
+                    const float ps   = ROWSCALE ? s_hi * s_lo : pm < MT / 2 ? s_lo : s_hi; // (row form: s_hi = the row scale read a row block ago)
                     const f4_t sv    = {ps, ps, ps, ps};
                     acc[0][pm]       = __builtin_elementwise_fma(pend0, sv, acc[0][pm]);
                     acc[1][pm]       = __builtin_elementwise_fma(pend1, sv, acc[1][pm]);
                 }
                 if constexpr(mt == 0)
                     s_lo = s_lo_next, s_hi = s_hi_next;
+                if constexpr(ROWSCALE)
+                    s_hi = row_s[16 * mt]; // this row block's row scale: used when its sums are folded in
                 if constexpr(mt == MT / 2)
                 {
                     // the scales of tile t + 1 (the tables hold one spare entry past the last tile)
                     const float sbn = tab_b[t + 1];
-                    s_lo_next = tab_a[2 * (t + 1)] * sbn, s_hi_next = tab_a[2 * (t + 1) + 1] * sbn;
+                    if constexpr(ROWSCALE)
+                        s_lo_next = sbn;
+                    else
+                        s_lo_next = tab_a[2 * (t + 1)] * sbn, s_hi_next = tab_a[2 * (t + 1) + 1] * sbn;
                 }
                 const f4_t zero = {0.f, 0.f, 0.f, 0.f};
                 pend0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], zero, 1, 0, 0, 0, 0, 0);
@@ -378,7 +427,8 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                     convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
                 if constexpr(mt == MT - 1) // (nothing is carried across the tile boundary)
                 {
-                    const f4_t sv = {s_hi, s_hi, s_hi, s_hi};
+                    const float ls = ROWSCALE ? s_hi * s_lo : s_hi;
+                    const f4_t sv  = {ls, ls, ls, ls};
                     acc[0][mt]    = __builtin_elementwise_fma(pend0, sv, acc[0][mt]);
                     acc[1][mt]    = __builtin_elementwise_fma(pend1, sv, acc[1][mt]);
                 }
@@ -519,6 +569,7 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
 }
 
 __global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256(const GemmParams p) { f8s_kernel_body<0>(p); }
-__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256_abscale(const GemmParams p) { f8s_kernel_body<0, true>(p); }
+__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256_abscale(const GemmParams p) { f8s_kernel_body<0, 1>(p); }
+__global__ __launch_bounds__(512, 2) void wq_gemm_f8_mfma_256_abscale_rows(const GemmParams p) { f8s_kernel_body<0, 2>(p); }
 
 } // namespace wq

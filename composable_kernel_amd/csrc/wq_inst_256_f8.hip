@@ -31,9 +31,10 @@ int launch_big_lds(K kernel, int lds_bytes, std::atomic<bool> (&opted_in)[64], c
 
 int launch_256_f8(const GemmParams& gp, dim3 grid, hipStream_t s, int variant)
 {
-    static std::atomic<bool> opted_s[64], opted_pp[64], opted_stamp[64], opted_ab[64];
-    if(gp.sa) // block-wise scales of both operands
-        return launch_big_lds(wq_gemm_f8_mfma_256_abscale, Mfma256F8S::LDS_BYTES_ABSCALE, opted_ab, gp, grid, s);
+    static std::atomic<bool> opted_s[64], opted_pp[64], opted_stamp[64], opted_ab[64], opted_abr[64];
+    if(gp.sa) // block-wise scales of both operands: activation scales per 128-row half of a tile, or per row
+        return gp.bm % 128 == 0 ? launch_big_lds(wq_gemm_f8_mfma_256_abscale, Mfma256F8S::LDS_BYTES_ABSCALE, opted_ab, gp, grid, s)
+                                : launch_big_lds(wq_gemm_f8_mfma_256_abscale_rows, Mfma256F8S::LDS_BYTES_ABSCALE, opted_abr, gp, grid, s);
     if(gp.dbg) // diagnostic: the stamped build of the ping-pong form
         return launch_big_lds(wq_gemm_f8_mfma_256_pp<true>, Mfma256F8::LDS_BYTES, opted_stamp, gp, grid, s);
     if(variant & WQ_FLAG_PINGPONG)

@@ -428,7 +428,7 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
     const bool fits_32bit = a_span * (is_f8 || p->a_dtype == WQ_I8 ? 1 : 2) <= 0x7FFFFFFFull && b_span <= 0x7FFFFFFFull;
     if(is_f8 && fits_32bit && !(p->flags & WQ_FLAG_GENERIC) && (p->a_dtype == WQ_F8_E4M3FN || (p->flags & WQ_FLAG_F8_NO_SPECIALS)) &&
        is_i4(p->b_dtype) && !(preshuf && (p->flags & WQ_FLAG_PINGPONG)) && !p->scale && p->a_layout == WQ_ROW_MAJOR && p->N % 256 == 0 &&
-       (!ab_scaled || (p->scale_block_k == 128 && p->scale_block_m % 128 == 0 && p->scale_block_n % 32 == 0 && p->K / 128 <= 640 &&
+       (!ab_scaled || (p->scale_block_k == 128 && p->scale_block_n % 32 == 0 && p->K / 128 <= 640 &&
                        !(p->flags & WQ_FLAG_PINGPONG))) &&
        plan.k_begin % 128 == 0 && plan.k_per_z % 128 == 0 && (plan.k_end - plan.k_begin) % 128 == 0 &&
        p->lda % 16 == 0 && p->ldb % 32 == 0 && p->ldc % 8 == 0 && (uintptr_t)p->a % 16 == 0 &&
@@ -1233,7 +1233,7 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
                  "DeviceGemmMultiplyMultiply_WeightQuant_Mfma_gfx950<512, 256, 256, 128, 16x16x128_f8f6f4, %s, %s, %s, "
                  "LdsDmaA, DirectB, ConvertInRegister, KBatch%d%s>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype), plan.k_batch,
-                 has_block_scales(p) ? ", ABScalePer128K" : "");
+                 !has_block_scales(p) ? "" : p->scale_block_m % 128 == 0 ? ", ABScalePer128K" : ", ABScalePer128K_RowScaleA");
     else if(plan.route == ROUTE_SKINNY_WS)
         snprintf(buf, n, "DeviceFpAintBGemm_SmallM_gfx950<256, 16, 16, 16x16x32, %s, %s, %s, StreamB, WavesSplitK>",
                  dt_name(p->a_dtype), dt_name(p->b_dtype), dt_name(p->c_dtype));
@@ -1269,7 +1269,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
              : plan.route == ROUTE_I8_MFMA256 ? "wq_gemm_i8_mfma_256"
-             : plan.route == ROUTE_F8_MFMA256 ? (has_block_scales(p) ? "wq_gemm_f8_mfma_256_abscale" : "wq_gemm_f8_mfma_256")
+             : plan.route == ROUTE_F8_MFMA256 ? (!has_block_scales(p) ? "wq_gemm_f8_mfma_256" : p->scale_block_m % 128 == 0 ? "wq_gemm_f8_mfma_256_abscale" : "wq_gemm_f8_mfma_256_abscale_rows")
              : plan.route == ROUTE_SKINNY ? "wq_gemm_skinny"
              : plan.route == ROUTE_SKINNY_WS
                  ? ((size_t)p->M * ((plan.k_end - plan.k_begin) * 2 + 16) <= 40 * 1024 ? "wq_gemm_skinny_ws" : "wq_gemm_skinny_wsc")

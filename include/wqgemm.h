@@ -152,8 +152,8 @@ typedef struct wqgemm_problem
      *              the descriptor the example gives its B1 tensor under B0Layout = ColumnMajor)
      *   C = epilogue( sum_k a'(m, k) * b'(k, n) ),  fp32 products and sums, k ascending.
      * The general kernel evaluates exactly that (bit-exact with the reference's host loop).  The fp8 matrix-core kernel
-     * (scale_block_k = 128, scale_block_m a multiple of 128, scale_block_n a multiple of 32, no more than 640 K tiles)
-     * sums each 128-k block exactly on the matrix core and applies a_scale * b_scale to the block's sum: the same value up
+     * (packed int4 weights, scale_block_k = 128, scale_block_n a multiple of 32, any scale_block_m -- 1 is one scale per
+     * token --, no more than 640 K tiles) sums each 128-k block exactly on the matrix core and applies a_scale * b_scale to the block's sum: the same value up
      * to fp32 rounding (identical when the scales are powers of two).  ld_a_scale >= ceil(K / scale_block_k),
      * ld_b_scale >= ceil(K / scale_block_k); 0 = exactly that.  k_batch and K slices (k_begin / k_end) combine with it: the tables
      * are indexed with the absolute k, and the fp32 partials carry the scales. */

@@ -139,7 +139,8 @@ def test_block_scales_with_an_epilogue_and_refusals(port):
                                b_block_scale=sb_t.data_ptr(), scale_block=block)
     assert not capi.is_supported(p16)
     # block sizes the matrix-core kernel does not take run on the general kernel
-    assert capi.kernel_name(prob(scale_block=(64, 128, 128))) == "wq_gemm_generic"
+    assert capi.kernel_name(prob(scale_block=(64, 128, 128))) == "wq_gemm_f8_mfma_256_abscale_rows"   # finer activation blocks
+    assert capi.kernel_name(prob(scale_block=(128, 16, 128))) == "wq_gemm_generic"
     assert capi.kernel_name(prob(scale_block=(128, 128, 64))) == "wq_gemm_generic"
 
 
@@ -184,3 +185,45 @@ def test_block_scales_planner_split_for_a_short_grid():
     np.testing.assert_array_equal(with_ws, without)
     gen = run(a, bp, sa, sb, M, N, K, block, 0, 0, flags=capi.FLAG_GENERIC, expect="wq_gemm_generic", **kw)
     np.testing.assert_array_equal(with_ws, gen)
+
+
+@pytest.mark.parametrize("M,N,K,bm,bn,fn,bf,kb", [(512, 512, 1024, 1, 128, True, True, 1), (300, 256, 384, 1, 128, False, False, 1),
+                                                  (256, 768, 128, 32, 64, True, False, 1), (640, 256, 2048, 100, 128, False, True, 1),
+                                                  (512, 512, 2048, 1, 128, True, True, 2), (1024, 1024, 4096, 1, 128, True, True, 1)])
+def test_per_row_activation_scales_on_the_matrix_core(port, M, N, K, bm, bn, fn, bf, kb):
+    """Activation scales finer than a 128-row tile half -- one per token (scale_block_m = 1, the usual serving recipe) or per
+    any other row block -- run on wq_gemm_f8_mfma_256_abscale_rows: the row scales of a K tile travel with it through LDS.
+    Exact data (small integers, power-of-two scales): bit-equal to the general kernel, which has the reference's arithmetic;
+    realistic data: within check_err's defaults of the checker."""
+    rng = np.random.default_rng(M + K + bm)
+    block = (bm, bn, 128)
+    kblocks = K // 128
+    ld_sa, ld_sb = kblocks + 1, kblocks
+    q = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    bp = pack_on_device(q, K, N)
+    kw = dict(bf16=bf, b_dtype=capi.I4_PACKED, a_dtype=capi.F8_E4M3FN if fn else capi.F8_FNUZ)
+    flags = 0 if fn else capi.FLAG_F8_NO_SPECIALS
+    rows_k = "wq_gemm_f8_mfma_256_abscale_rows"
+    # exact set
+    one = 0x38 if fn else 0x40
+    lut = np.array([0x80 | (one + 8), 0x80 | one, 0, one, one + 8], np.uint8)
+    a = lut[rng.integers(0, 5, (M, K))]
+    sa = np.exp2(rng.integers(-4, 1, ((M + bm - 1) // bm, ld_sa))).astype(np.float32)
+    sb = np.exp2(rng.integers(-4, 1, ((N + bn - 1) // bn, ld_sb))).astype(np.float32)
+    got = run(a, bp, sa, sb, M, N, K, block, ld_sa, ld_sb, flags=flags, expect=rows_k, k_batch=kb, **kw)
+    gen = run(a, bp, sa, sb, M, N, K, block, ld_sa, ld_sb, flags=capi.FLAG_GENERIC, expect="wq_gemm_generic", **kw)
+    np.testing.assert_array_equal(got, gen)
+    # realistic set
+    a = (rng.integers(24, 88, (M, K)) + 128 * rng.integers(0, 2, (M, K))).astype(np.uint8)
+    sa = rng.uniform(0.05, 1.0, sa.shape).astype(np.float32)
+    sb = rng.uniform(0.05, 1.0, sb.shape).astype(np.float32)
+    got = run(a, bp, sa, sb, M, N, K, block, ld_sa, ld_sb, flags=flags, expect=rows_k, k_batch=kb, **kw)
+    rows = min(M, 20)
+    exp = port.gemm_f8_i8_abscale(a[:rows], q, sa, sb, rows, N, K, K, K, N, block, ld_sa, ld_sb, e_bf16=bf, e4m3fn=fn).reshape(rows, N)
+    dt = capi.BF16 if bf else capi.F16
+    tol = 1e-2 if bf else 1e-3
+    check_err(bits_to_f32(got[:rows], dt), bits_to_f32(exp, dt), tol, tol)
+    tail = run(a[M - 8:], bp, sa[(M - 8) // bm:], sb, 8, N, K, block, ld_sa, ld_sb, flags=capi.FLAG_GENERIC, expect="wq_gemm_generic", **kw) \
+        if (M - 8) % bm == 0 else None
+    if tail is not None:   # the last rows too (a partial last row tile for M = 300)
+        check_err(bits_to_f32(got[M - 8:], dt), bits_to_f32(tail, dt), tol, tol)

@@ -131,6 +131,12 @@ def main():
                                      flags=flags, a_block_scale=sa.data_ptr(), b_block_scale=sb.data_ptr(),
                                      scale_block=(128, 128, 128))
             emit(f"fp8 x int4 {M}x{N}x{K}, 128x128x128 block scales of A and B ({tag})", "f8", p, None, M, N, K, nbytes)
+        # the same with one activation scale per token and 128 k (scale_block_m = 1)
+        sa1 = torch.rand((M, K // 128), generator=g, device=dev)
+        p = capi.fpAintB_problem(a.data_ptr(), b.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.F8_E4M3FN, c_dtype=capi.BF16,
+                                 a_block_scale=sa1.data_ptr(), b_block_scale=sb.data_ptr(), scale_block=(1, 128, 128))
+        emit(f"fp8 x int4 {M}x{N}x{K}, 1x128 activation scales, 128x128 weight scales (E4M3FN)", "f8", p, None, M, N, K,
+             nbytes + 4 * (sa1.numel() - sa.numel()))
 
     if args.out:
         with open(args.out, "w") as fh:

@@ -264,7 +264,7 @@ def one_case_ab(rng) -> dict:
     fn = bool(rng.integers(0, 2))
     bf = bool(rng.integers(0, 2))
     kind = int(rng.integers(0, 3))   # packed int4, pre-shuffled int4, int8
-    bm = int(rng.choice([128, 128, 256, 64]))
+    bm = int(rng.choice([128, 128, 256, 64, 1, 1, 48]))
     bn = int(rng.choice([128, 128, 32, 64, 256, 16]))
     bk = int(rng.choice([128, 128, 128, 64, 256]))
     q = rng.integers(-8, 8, (N, K)).astype(np.int8)
@@ -299,8 +299,9 @@ def one_case_ab(rng) -> dict:
     if not capi.is_supported(probe):   # (pre-shuffled weights with a block shape only the general kernel takes: refused by design)
         return {"skipped": capi.lib.wqgemm_last_error().decode()}
     kernel = capi.kernel_name(probe).split("+")[0]   # (a planner's or caller's split appends the reduce stage)
-    want_mfma = kind != 2 and bk == 128 and bm % 128 == 0 and bn % 32 == 0
-    assert (kernel == "wq_gemm_f8_mfma_256_abscale") == want_mfma, (kernel, bm, bn, bk, kind, kb)
+    want = "wq_gemm_generic" if (kind == 2 or bk != 128 or bn % 32) else \
+        "wq_gemm_f8_mfma_256_abscale" if bm % 128 == 0 else "wq_gemm_f8_mfma_256_abscale_rows"
+    assert kernel == want, (kernel, want, bm, bn, bk, kind, kb)
     got = run_fpaintb(a, b, None, M, N, K, flags=flags, k_batch=kb, use_workspace=bool(kb > 1 or rng.integers(0, 3)), **kw)
     desc = dict(fmt=("i4", "i4pre", "i8")[kind], e4m3fn=fn, bf16=bf, M=M, N=N, K=K, lda=lda, ldc=kw.get("ldc", N), block=[bm, bn, bk],
                 ld_scales=[ld_sa, ld_sb], k_batch=kb, kernel=kernel)
