@@ -4,10 +4,11 @@
 // tensors and strides, Perf line, host check: operands scaled to fp32, ReferenceGemm<float, float>, convert, check_err
 // at 5e-2) -- with weight-quantized B in place of fp8 B.
 //
-//   example_gemm_ab_scale_fp8_int4_gfx950 [verify init time_kernel [M N K [fmt]]]
+//   example_gemm_ab_scale_fp8_int4_gfx950 [verify init time_kernel [M N K [fmt [per_token]]]]
 //     init: 1 integer values and power-of-two scales (every block sum exact: bit-exact check), otherwise fp8 bytes of
 //           8 binades and uniform scales in (0, 1)
 //     fmt:  1 FNUZ bytes on the fp8 matrix core (the generated data holds none of 0x7F / 0xFF / 0x80), 2 E4M3FN bytes
+//     per_token: 1 = one activation scale per row and 128 k (ScaleBlockM = 1) instead of per 128 rows
 #include <iostream>
 #include <random>
 
@@ -27,11 +28,10 @@ using PassThrough = ck::tensor_operation::element_wise::PassThrough;
 using EDataType   = ck::bhalf_t;
 using BDataType   = ck::wq_int4x2_t;
 
-static constexpr ck::index_t Scale_Block_M = 128;
 static constexpr ck::index_t Scale_Block_N = 128;
 static constexpr ck::index_t Scale_Block_K = 128;
 
-template <typename ADataType, bool NoSpecials>
+template <typename ADataType, bool NoSpecials, ck::index_t Scale_Block_M>
 int run(bool do_verification, int init_method, bool time_kernel, ck::index_t M, ck::index_t N, ck::index_t K)
 {
     using DeviceOp = ck::tensor_operation::device::DeviceGemmMultiD_ABScale_WeightQuant_gfx950<
@@ -148,12 +148,17 @@ int main(int argc, char* argv[])
         M = std::stoi(argv[4]), N = std::stoi(argv[5]), K = std::stoi(argv[6]);
     if(argc >= 8)
         fmt = std::stoi(argv[7]);
-    if(argc == 2 || argc == 3 || argc == 5 || argc == 6 || argc > 8)
+    const bool per_token = argc >= 9 && std::stoi(argv[8]) != 0;
+    if(argc == 2 || argc == 3 || argc == 5 || argc == 6 || argc > 9)
     {
         std::cerr << "arg1: verification (0=no, 1=yes)\narg2: initialization (1=integer value, 2=decimal value)\n"
-                     "arg3: time kernel (0=no, 1=yes)\narg4 to 6: M, N, K\narg7: 1 FNUZ bytes, 2 E4M3FN bytes\n";
+                     "arg3: time kernel (0=no, 1=yes)\narg4 to 6: M, N, K\narg7: 1 FNUZ bytes, 2 E4M3FN bytes\n"
+                     "arg8: 1 = one activation scale per token (ScaleBlockM = 1)\n";
         return 1;
     }
-    return fmt == 2 ? run<ck::wq_f8_e4m3fn_t, false>(do_verification, init_method, time_kernel, M, N, K)
-                    : run<ck::f8_t, true>(do_verification, init_method, time_kernel, M, N, K);
+    if(per_token)
+        return fmt == 2 ? run<ck::wq_f8_e4m3fn_t, false, 1>(do_verification, init_method, time_kernel, M, N, K)
+                        : run<ck::f8_t, true, 1>(do_verification, init_method, time_kernel, M, N, K);
+    return fmt == 2 ? run<ck::wq_f8_e4m3fn_t, false, 128>(do_verification, init_method, time_kernel, M, N, K)
+                    : run<ck::f8_t, true, 128>(do_verification, init_method, time_kernel, M, N, K);
 }

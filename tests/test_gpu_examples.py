@@ -176,6 +176,14 @@ def test_fp8_int4_multiply_multiply_example(fmt, gelu, init):
     assert ("16x16x128_f8f6f4" in r.stdout) == (fmt != 0) and "Mfma" in r.stdout
 
 
+@pytest.mark.parametrize("fmt,init", [(1, 1), (2, 2)])
+def test_fp8_int4_ab_scale_example_per_token(fmt, init):
+    """The same flow with one activation scale per token and 128 k (ScaleBlockM = 1): the row-scale form of the kernel."""
+    r = _run(os.path.join(EX, "example_gemm_ab_scale_fp8_int4_gfx950"), 1, init, 1, 640, 768, 1024, fmt, 1)
+    assert r.returncode == 0 and "verification: PASS" in r.stdout, r.stdout + r.stderr
+    assert "RowScaleA" in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("fmt,init", [(1, 1), (2, 1), (1, 2), (2, 2)])
 def test_fp8_int4_ab_scale_example(fmt, init):
     """example/65's block-scaled flow (fp8 A with a scale per 128 x 128 block, weights with a scale per 128 x 128 block,
