@@ -689,6 +689,105 @@ __global__ __launch_bounds__(256) void wq_gemm_i8_mfma_128(const I8GemmParams p)
 }
 
 
+// The same GEMM for M <= 16 rows of activations (decode): one pass over the weights, bound by HBM bandwidth.
+//   grid  (N / (16 NB), 1, k slices), 256 threads: the four waves of a workgroup own the same NB blocks of 16 columns and a
+//         quarter of the workgroup's K range each (dealt in units of P 64-k steps; the first (units % 4) waves take one more).
+//   lane  (fr, fq) streams column fr of each of its blocks: the 16 bytes at k = 64 step + 16 fq are one operand of
+//         v_mfma_i32_16x16x64_i8 as they arrive, P NB loads in flight; the activations of row fr at the same k (from L2;
+//         lanes of rows past M read nothing and feed rows that are never stored) are the other, fetched once for the NB
+//         blocks -- at M = 16 the activation reads of NB = 1 are as many L2 requests as the weight stream itself.
+//   The four partial sums meet in LDS (integer sums: exact in any order); wave nb requantises block nb and stores 4 int8
+//   per lane, or stores its int32 sums to slab blockIdx.z of `partial` for wq_reduce_requant_i8.
+template <int P, int NB>
+__global__ __launch_bounds__(256) void wq_gemm_i8_skinny(const I8GemmParams p)
+{
+    __shared__ i4_t red[4 * NB * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * (16 * NB);
+
+    // K range of this workgroup (the host makes every slice a positive multiple of 64 P)
+    const int kz0    = p.partial ? blockIdx.z * p.k_tiles_per_z * 128 : 0;
+    const int klen   = p.partial ? min(p.K - kz0, p.k_tiles_per_z * 128) : p.K;
+    const int units  = klen / (64 * P);
+    const int ubase  = units >> 2, urem = units & 3;
+    const int nsteps = (ubase + (wave < urem ? 1 : 0)) * P;
+    // (a wave without work still issues its first loads: it points them at the start of the range)
+    const int kbeg   = kz0 + (nsteps ? (wave * ubase + min(wave, urem)) * (64 * P) : 0);
+
+    const uint8_t* bptr[NB];
+#pragma unroll
+    for(int nb = 0; nb < NB; ++nb)
+        bptr[nb] = (const uint8_t*)p.b + (size_t)(n0 + nb * 16 + fr) * p.ldb + kbeg + fq * 16;
+    // activations through a buffer resource that ends with row M - 1: lanes of the rows past it carry an offset
+    // beyond the end, which reads as zero without touching memory
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.K), 0x00020000);
+    const uint32_t a_voff = fr < p.M ? (uint32_t)fr * (uint32_t)p.lda + (uint32_t)(kbeg + fq * 16) : 0x7F000000u;
+
+    i4_t wraw[NB][P], araw[P];
+#pragma unroll
+    for(int i = 0; i < P; ++i)
+    {
+        const int st = min(i, max(nsteps - 1, 0));
+#pragma unroll
+        for(int nb = 0; nb < NB; ++nb)
+            wraw[nb][i] = *(const i4_t*)(bptr[nb] + (size_t)st * 64);
+        araw[i] = __builtin_bit_cast(i4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff + st * 64, 0, 0));
+    }
+    i4_t acc[NB];
+#pragma unroll
+    for(int nb = 0; nb < NB; ++nb)
+        acc[nb] = i4_t{0, 0, 0, 0};
+    for(int t = 0; t < nsteps; t += P)
+    {
+#pragma unroll
+        for(int i = 0; i < P; ++i)
+        {
+            const i4_t a  = araw[i];
+            const int nxt = min(t + i + P, nsteps - 1);
+            i4_t w[NB];
+#pragma unroll
+            for(int nb = 0; nb < NB; ++nb)
+            {
+                w[nb]       = wraw[nb][i];
+                wraw[nb][i] = *(const i4_t*)(bptr[nb] + (size_t)nxt * 64);
+            }
+            araw[i] = __builtin_bit_cast(i4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff + nxt * 64, 0, 0));
+#pragma unroll
+            for(int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[nb], a, acc[nb], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for(int nb = 0; nb < NB; ++nb)
+        red[(wave * NB + nb) * 64 + lane] = acc[nb];
+    __syncthreads();
+    if(wave >= NB || fr >= p.M)
+        return;
+    i4_t v = red[wave * 64 + lane]; // block `wave` of wave 0, then of waves 1 .. 3
+#pragma unroll
+    for(int w = 1; w < 4; ++w)
+    {
+        const i4_t u = red[(w * NB + wave) * 64 + lane];
+        v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+    }
+    const int m = fr, n = n0 + wave * 16 + fq * 4;
+    if(p.partial)
+    {
+        *(i4_t*)(p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n) = v;
+        return;
+    }
+    i4_t bias4 = {0, 0, 0, 0};
+    if(p.kind >= 11)
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+            bias4[j] = p.bias[n + j];
+    *(uint32_t*)((int8_t*)p.c + (size_t)m * p.ldc + n) = requant_pack4(v, bias4, requant_relu_floor(p.kind), p.requant);
+}
+
 // The same GEMM on 256 x 256 x 128 tiles for problems that fill the chip: 8 waves in a 2 x 4 grid (each 128 rows x 64
 // columns = 8 x 4 accumulator fragments), both operands by LDS-DMA into a two-stage ring (2 x 64 KiB), 24 fragment
 // reads for 64 MFMAs per K tile and wave (the 128-tile kernel: 16 for 32), and the requantised int8 tile staged

@@ -61,6 +61,7 @@ enum Route
     ROUTE_MFMA128,
     ROUTE_MFMA256,
     ROUTE_I8_MFMA128,
+    ROUTE_I8_SKINNY,
     ROUTE_I8_MFMA256,
     ROUTE_F8_MFMA256,
     ROUTE_SKINNY,
@@ -234,6 +235,24 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
                     plan.k_per_z    = per;
                     plan.partial    = true;
                 }
+            }
+        }
+        // M <= 16 (decode): one pass over the weights on the streaming kernel.  Its workgroups own 16 columns each; fewer
+        // than 256 of them leave CUs idle, so K is split across blockIdx.z (optional workspace, as above) in slices of
+        // at least 1024 k up to about 512 workgroups.
+        if(tiled_i8 && p->M <= 16 && p->N % 16 == 0 && p->K >= 256 && !(p->flags & (WQ_FLAG_TILE_128 | WQ_FLAG_TILE_256)) &&
+           (long)(p->M - 1) * p->lda + p->K < 0x7F000000L)
+        {
+            plan.route      = ROUTE_I8_SKINNY;
+            plan.auto_split = false, plan.partial = false, plan.k_batch = 1, plan.k_per_z = p->K;
+            const int wgs = p->N / 16;
+            if(wgs < 256 && p->K % 256 == 0 && p->K >= 2048)
+            {
+                int kb        = std::min((512 + wgs - 1) / wgs, p->K / 1024);
+                const int per = wqgemm_splitk_kread(p->K, kb, 256);
+                kb            = (p->K + per - 1) / per;
+                if(kb > 1)
+                    plan.auto_split = true, plan.k_batch = kb, plan.k_per_z = per, plan.partial = true;
             }
         }
         if((p->flags & WQ_FLAG_TILE_256) && plan.route != ROUTE_I8_MFMA256)
@@ -821,6 +840,42 @@ int launch_main(const wqgemm_problem* p, const Plan& plan, void* workspace, hipS
         }
         hipLaunchKernelGGL(wq::wq_gemm_i8_mfma_256, dim3(gp.tiles_m * gp.tiles_n), dim3(512), wq::kI8Tile256Lds, s, gp);
     }
+    else if(plan.route == ROUTE_I8_SKINNY)
+    {
+        wq::I8GemmParams gp;
+        gp.a = p->a, gp.b = p->b, gp.c = p->c;
+        gp.M = p->M, gp.N = p->N, gp.K = p->K;
+        gp.lda = p->lda, gp.ldb = p->ldb, gp.ldc = p->ldc;
+        gp.tiles_m = 1, gp.tiles_n = p->N / 16, gp.group_m = 1;
+        gp.requant = p->requant_scale;
+        gp.kind    = p->epilogue;
+        gp.bias    = (const int32_t*)p->d0;
+        gp.partial = plan.partial ? (int32_t*)workspace : nullptr;
+        gp.k_tiles_per_z = plan.k_per_z / 128;
+        // NB blocks of 16 columns per workgroup share each activation fetch (two, four past 8 rows: the activation reads
+        // weigh M / 16 of the weight reads) as long as that leaves a workgroup per CU; about eight loads in flight per lane,
+        // and every slice a multiple of 64 P (the last slice is K minus whole slices)
+        const int per = plan.k_per_z;
+        int nb        = p->M <= 8 ? 2 : 4;
+        while(nb > 1 && (p->N % (16 * nb) != 0 || p->N / (16 * nb) * (plan.partial ? plan.k_batch : 1) < 256))
+            nb >>= 1;
+        const bool k512 = per % 512 == 0 && p->K % 512 == 0 && per >= 2048, k256 = per % 256 == 0 && p->K % 256 == 0 && per >= 1024;
+        const dim3 grid(p->N / (16 * nb), 1, plan.partial ? plan.k_batch : 1);
+#define WQ_I8_SKINNY(P_, NB_) hipLaunchKernelGGL((wq::wq_gemm_i8_skinny<P_, NB_>), grid, dim3(256), 0, s, gp)
+        if(nb == 4)
+        {
+            if(k256) WQ_I8_SKINNY(2, 4); else WQ_I8_SKINNY(1, 4);
+        }
+        else if(nb == 2)
+        {
+            if(k256) WQ_I8_SKINNY(4, 2); else WQ_I8_SKINNY(1, 2);
+        }
+        else
+        {
+            if(k512) WQ_I8_SKINNY(8, 1); else if(k256) WQ_I8_SKINNY(4, 1); else WQ_I8_SKINNY(1, 1);
+        }
+#undef WQ_I8_SKINNY
+    }
     else if(plan.route == ROUTE_I8_MFMA128)
     {
         wq::I8GemmParams gp;
@@ -1226,6 +1281,8 @@ int wqgemm_type_string(const wqgemm_problem* p, char* buf, size_t n)
     }
     if(plan.route == ROUTE_I8_MFMA128)
         snprintf(buf, n, "DeviceGemmQuantization_Mfma_gfx950<256, 128, 128, 128, 16x16x64, I8, I8, I8, LdsDma>");
+    else if(plan.route == ROUTE_I8_SKINNY)
+        snprintf(buf, n, "DeviceGemmQuantization_SmallM_gfx950<256, 16, 16, 16x16x64, I8, I8, I8, StreamB, WavesSplitK, KBatch%d>", plan.k_batch);
     else if(plan.route == ROUTE_I8_MFMA256)
         snprintf(buf, n, "DeviceGemmQuantization_Mfma_gfx950<512, 256, 256, 128, 16x16x64, I8, I8, I8, LdsDma>");
     else if(plan.route == ROUTE_F8_MFMA256)
@@ -1268,6 +1325,7 @@ int wqgemm_kernel_name(const wqgemm_problem* p, char* buf, size_t n)
     snprintf(buf, n, "%s%s", plan.via_f16 ? "wq_f8_fnuz_to_f16+" : (plan.via_colb ? "wq_transpose_b8+" : ""),
              plan.route == ROUTE_MFMA256      ? "wq_gemm_mfma_256"
              : plan.route == ROUTE_I8_MFMA128 ? "wq_gemm_i8_mfma_128"
+             : plan.route == ROUTE_I8_SKINNY  ? "wq_gemm_i8_skinny"
              : plan.route == ROUTE_I8_MFMA256 ? "wq_gemm_i8_mfma_256"
              : plan.route == ROUTE_F8_MFMA256 ? (!has_block_scales(p) ? "wq_gemm_f8_mfma_256" : p->scale_block_m % 128 == 0 ? "wq_gemm_f8_mfma_256_abscale" : "wq_gemm_f8_mfma_256_abscale_rows")
              : plan.route == ROUTE_SKINNY ? "wq_gemm_skinny"

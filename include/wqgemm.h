@@ -185,8 +185,8 @@ int wqgemm_is_supported(const wqgemm_problem* p);
  *  - k_batch*M*N*4 when the caller sets k_batch > 1 (required: the launch fails with WQ_ERR_WORKSPACE
  *    without it), plus K*N for tile-aligned row-major (K x N) 8-bit weights (their K-contiguous copy follows the slabs);
  *  - kb*M*N*4 when the planner itself splits K (small-M problems; grids shorter than the chip on the 128- and 256-tile
- *    kernels, the fp8 kernel and the int8 x int8 128-tile kernel, whose partials are int32; kb chosen so the grid
- *    fills the chip;
+ *    kernels, the fp8 kernel and the int8 x int8 128-tile and small-M kernels, whose partials are int32; kb chosen so the
+ *    grid fills the chip;
  *    optional: without it the launch runs the whole K range as one slice);
  *  - (M*K + N)*2 for tile-aligned WQ_F8_FNUZ activations without WQ_FLAG_F8_NO_SPECIALS (optional: holds the
  *    fp16 image of A for the fp16 matrix-core kernel), and for fp8 activations of either format at M <= 16 when the

@@ -87,6 +87,10 @@ def test_int8_requant_routes():
     assert capi.kernel_name(_i8_problem(M=256, N=256, K=256)) == "wq_gemm_i8_mfma_128"     # the example's size
     assert capi.kernel_name(_i8_problem(M=256, N=256, K=256, flags=capi.FLAG_TILE_256)) == "wq_gemm_i8_mfma_256"
     assert capi.kernel_name(_i8_problem(M=1000)) == "wq_gemm_i8_mfma_128"                  # partial last row tile
+    assert capi.kernel_name(_i8_problem(M=16)) == "wq_gemm_i8_skinny"                      # decode: one pass over the weights
+    assert capi.kernel_name(_i8_problem(M=16, flags=capi.FLAG_TILE_128)) == "wq_gemm_i8_mfma_128"
+    assert capi.kernel_name(_i8_problem(M=17)) == "wq_gemm_i8_mfma_128"
+    assert capi.workspace_bytes(_i8_problem(M=4, N=1024)) == 4 * 4 * 1024 * 4             # 64 workgroups: four K slices of 1024
     assert capi.kernel_name(_i8_problem(N=1000)) == "wq_gemm_i8_mfma_128"                  # partial last column tile
     assert capi.kernel_name(_i8_problem(N=1002)) == "wq_gemm_generic"
     assert capi.kernel_name(_i8_problem(K=200, lda=200, ldb=200)) == "wq_gemm_generic"

@@ -684,7 +684,7 @@ def test_int8_bias_relu_requant(golden_gemm, port):
     # ragged M stays on the matrix core: partial last row tile, guard rows after E untouched
     for Mr in (1, 100, 333):
         ar = np.ascontiguousarray(a[:Mr])
-        e, name = _run_i8(ar, b, Mr, N, K, 2e-4, bias=bias, relu=True)
+        e, name = _run_i8(ar, b, Mr, N, K, 2e-4, bias=bias, relu=True, flags=capi.FLAG_TILE_128)
         assert name == "wq_gemm_i8_mfma_128"
         ref = port.gemm_i8_bias_requant(ar, b, bias, Mr, N, K, K, K, N, 2e-4, 1).reshape(Mr, N)
         np.testing.assert_array_equal(e, ref)
@@ -1595,7 +1595,7 @@ def test_random_shapes_int8_requant_against_the_general_kernel():
         assert gname == GENERIC and name != GENERIC
         names.add(name)
         np.testing.assert_array_equal(e, g, err_msg=f"case {case}: M={M} N={N} K={K} bias={bias is not None} relu={relu}")
-    assert names == {"wq_gemm_i8_mfma_128", "wq_gemm_i8_mfma_256"}
+    assert names == {"wq_gemm_i8_mfma_128", "wq_gemm_i8_mfma_256", "wq_gemm_i8_skinny"}
 
 
 def test_random_shapes_f8_int4_against_the_general_kernel():
@@ -1680,7 +1680,9 @@ def test_int8_requant_planner_split_k(port):
         e, name = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu)
         p = capi.fpAintB_problem(1 << 20, 1 << 20, None, 1 << 20, M, N, K, a_dtype=capi.I8, b_dtype=capi.I8, c_dtype=capi.I8,
                                  epilogue=capi.EPI_ACT_MUL_CLAMP, requant=rq)
-        assert name == "wq_gemm_i8_mfma_128" and capi.workspace_bytes(p) > 0 and "KBatch1>" not in capi.type_string(p), capi.type_string(p)
+        assert name == ("wq_gemm_i8_skinny" if M <= 16 else "wq_gemm_i8_mfma_128")
+        if M > 1:
+            assert capi.workspace_bytes(p) > 0 and "KBatch1>" not in capi.type_string(p), capi.type_string(p)
         one, _ = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu, use_workspace=False)
         g, gname = _run_i8(a, b, M, N, K, rq, bias=bias, relu=relu, flags=capi.FLAG_GENERIC)
         assert gname == GENERIC
@@ -1689,6 +1691,41 @@ def test_int8_requant_planner_split_k(port):
         if bias is None and not relu:
             exp = port.gemm_i8_requant(a, b, M, N, K, K, K, N, rq).reshape(M, N)
             np.testing.assert_array_equal(e, exp)
+
+
+def test_int8_requant_decode_on_the_streaming_kernel(port):
+    """M <= 16 of the int8 x int8 GEMM: one pass over the weights on the streaming kernel, K dealt to the four waves of a
+    workgroup (unevenly when it does not divide) and, for few columns, to several workgroups.  Integer arithmetic: bit-equal
+    to the general kernel, to the 128-tile kernel and to the CPU checker; bias, Relu, padded rows of every operand, with and
+    without the optional workspace."""
+    rng = np.random.default_rng(1616)
+    cases = [(1, 16, 256), (3, 48, 384), (16, 256, 640), (7, 1024, 1024), (16, 4096, 4096), (2, 11008, 4096), (16, 64, 8192),
+             (5, 2048, 2304), (1, 512, 4608), (12, 4096, 1280), (16, 1024, 14336), (4, 128, 3072)]
+    for i, (M, N, K) in enumerate(cases):
+        a = rng.integers(-128, 128, (M, K + (32 if i % 3 == 1 else 0))).astype(np.int8)
+        b = rng.integers(-128, 128, (N, K + (16 if i % 2 else 0))).astype(np.int8)
+        bias = rng.integers(-50000, 50001, N).astype(np.int32) if i % 2 else None
+        kw = dict(bias=bias, relu=bool(i % 3 == 0), lda=a.shape[1], ldb=b.shape[1], ldc=N + (12 if i % 4 == 2 else 0))
+        rq = 0.0007
+        e, name = _run_i8(a, b, M, N, K, rq, **kw)
+        assert name == "wq_gemm_i8_skinny", (M, N, K, name)
+        one, _ = _run_i8(a, b, M, N, K, rq, use_workspace=False, **kw)
+        t, tname = _run_i8(a, b, M, N, K, rq, flags=capi.FLAG_TILE_128, **kw)
+        g, gname = _run_i8(a, b, M, N, K, rq, flags=capi.FLAG_GENERIC, **kw)
+        assert gname == GENERIC and tname == "wq_gemm_i8_mfma_128"
+        for got in (e, one, t):
+            np.testing.assert_array_equal(got[:, :N], g[:, :N], err_msg=f"M={M} N={N} K={K}")
+        assert (e[:, N:] == 77).all()
+        if bias is None and not kw["relu"] and a.shape[1] == K and b.shape[1] == K:
+            np.testing.assert_array_equal(e[:, :N], port.gemm_i8_requant(a, b, M, N, K, K, K, N, rq).reshape(M, N))
+    # saturating sums: every product 127 * 127 or -128 * 127
+    M, N, K = 16, 256, 2048
+    a = np.full((M, K), 127, np.int8)
+    b = np.where(np.arange(N)[:, None] % 2 == 0, 127, -128).astype(np.int8) * np.ones((1, K), np.int8)
+    e, name = _run_i8(a, b, M, N, K, 1e-5)
+    g, _ = _run_i8(a, b, M, N, K, 1e-5, flags=capi.FLAG_GENERIC)
+    assert name == "wq_gemm_i8_skinny"
+    np.testing.assert_array_equal(e, g)
 
 
 @pytest.mark.parametrize("fn", [True, False])

@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--b", default="i4", choices=("i4", "i8"))
+    ap.add_argument("--a", default="f16", choices=("f16", "i8"), help="i8: the int8 x int8 requantised GEMM (int8 weights and output)")
+    ap.add_argument("--flags", type=int, default=0, help="planner flags (e.g. 1 = the 128-tile kernel) for comparisons")
     ap.add_argument("--group-k", type=int, default=0, help="group-wise weight scales: k per group (fp16 activations)")
     ap.add_argument("--pre", action="store_true", help="weights in the pre-shuffled order (random bytes either way)")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008,8192x8192,28672x8192,8192x28672")
@@ -31,6 +33,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="time replays of a HIP graph holding 40 launches (no per-launch host work) instead of plain launches")
     args = ap.parse_args()
+    if args.a == "i8":
+        args.b = "i8"
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(3)
@@ -67,11 +71,18 @@ def main():
             bdt = capi.I8_PRESHUFFLED if args.pre else capi.I8
         s = (torch.rand((K // args.group_k, N) if args.group_k else (N,), generator=g, device=dev) * 0.01 + 0.001).half()
         for M in (int(v) for v in args.ms.split(",")):
-            a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).half()
-            c = torch.empty((M, N), dtype=torch.float16, device=dev)
-            probs = [capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K, b_dtype=bdt,
-                                          scale_group_k=args.group_k)
-                     for w in ws]
+            if args.a == "i8":
+                a = torch.randint(-128, 128, (M, K), generator=g, device=dev, dtype=torch.int8)
+                c = torch.empty((M, N), dtype=torch.int8, device=dev)
+                probs = [capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), None, c.data_ptr(), M, N, K, a_dtype=capi.I8, b_dtype=capi.I8,
+                                              c_dtype=capi.I8, epilogue=capi.EPI_ACT_MUL_CLAMP, requant=1e-3, flags=args.flags)
+                         for w in ws]
+            else:
+                a = (torch.rand((M, K), generator=g, device=dev) * 2 - 1).half()
+                c = torch.empty((M, N), dtype=torch.float16, device=dev)
+                probs = [capi.fpAintB_problem(a.data_ptr(), w.data_ptr(), s.data_ptr(), c.data_ptr(), M, N, K, b_dtype=bdt,
+                                              scale_group_k=args.group_k, flags=args.flags)
+                         for w in ws]
             nb = max(capi.workspace_bytes(p) for p in probs)
             wsp = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -100,8 +111,8 @@ def main():
 
             run(200)
             ms = statistics.median(run(40) for _ in range(5))
-            nbytes = wbytes + 2 * M * K + 2 * M * N + 2 * N
-            line = {"N": N, "K": K, "M": M, "b": args.b + ("_preshuffled" if args.pre else ""), "kernel": capi.kernel_name(probs[0]), "us": ms * 1e3,
+            nbytes = wbytes + M * K + M * N if args.a == "i8" else wbytes + 2 * M * K + 2 * M * N + 2 * N
+            line = {"N": N, "K": K, "M": M, "a": args.a, "workspace_bytes": nb, "b": args.b + ("_preshuffled" if args.pre else ""), "kernel": capi.kernel_name(probs[0]), "us": ms * 1e3,
                     "algorithmic_bytes": nbytes, "hbm_gbps": nbytes / (ms * 1e-3) / 1e9,
                     "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM, "weight_copies_rotated": copies,
                     "hip_graph": bool(args.graph), "scale_group_k": args.group_k}

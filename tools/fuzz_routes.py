@@ -178,9 +178,9 @@ def _run_i8(a, b, M, N, K, requant, flags, lda, ldb, ldc, bias, relu, use_worksp
 
 def one_case_i8(rng) -> dict:
     """int8 x int8 -> int8 behind the requantisation epilogues: integer accumulation, so random data is exact."""
-    M = int(rng.choice([1, 5, 16, 64, 100, 128, 200, 256, 300, 513, 1024, 2048]))
-    N = int(rng.choice([16, 100, 128, 256, 384, 512, 1024, 2048, 4096]))
-    K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 4096, 5120, 8192]))
+    M = int(rng.choice([1, 2, 5, 9, 12, 16, 64, 100, 128, 200, 256, 300, 513, 1024, 2048]))
+    N = int(rng.choice([16, 48, 100, 128, 256, 384, 512, 1024, 2048, 4096, 8192]))
+    K = int(rng.choice([128, 256, 384, 640, 1024, 2048, 2304, 4096, 5120, 8192]))
     lda, ldb, ldc = K + int(rng.choice([0, 0, 16, 128])), K + int(rng.choice([0, 0, 16, 128])), N + int(rng.choice([0, 0, 16]))
     a = rng.integers(-128, 128, (M, lda)).astype(np.int8)
     b = rng.integers(-128, 128, (N, ldb)).astype(np.int8)
