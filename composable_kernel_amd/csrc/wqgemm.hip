@@ -212,7 +212,8 @@ int make_plan(const wqgemm_problem* p, Plan& plan, bool have_workspace = true)
         // optional workspace, requantised by wq_reduce_requant_i8; one slice without a workspace).  Two workgroups
         // share a CU, so the slice count is the one with the shortest chain on the busiest CU, as for the 16-bit
         // 128-tile kernel below; slices in whole 128-k tiles, at least 512 k (1024 k once a CU holds two).
-        if(plan.route == ROUTE_I8_MFMA128 && wgs128 <= 128 && !(p->flags & WQ_FLAG_TILE_128))
+        // (up to 256 workgroups; two halves of K for 257 ... 511 workgroups, which pay on the 16-bit kernel, lose 15 - 30 % here)
+        if(plan.route == ROUTE_I8_MFMA128 && wgs128 <= 256 && !(p->flags & WQ_FLAG_TILE_128))
         {
             int best_score = 0, kb = 1;
             for(int c = 1; c <= 16 && wgs128 * c <= 512; ++c)
