@@ -120,3 +120,33 @@ def test_noalloc_optional_scratch_dropped_and_no_scratch_needed():
         outs.append(host_u16(c_t).copy())
     np.testing.assert_array_equal(outs[1], outs[0])
     assert (outs[0] != 0x7BFF).all()
+
+
+def test_noalloc_int8_planner_split_uses_the_scratch():
+    """The planner's own K split of the int8 x int8 GEMM (int32 partials) through the built-in scratch: the small-M streaming
+    kernel and the 128-tile kernel, same bits as with a caller workspace and as the single-slice launch without one."""
+    rng = np.random.default_rng(99)
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K, kernel) in ((300, 1024, 8192, "wq_gemm_i8_mfma_128"), (8, 1024, 4096, "wq_gemm_i8_skinny")):
+        a_t = dev(rng.integers(-128, 128, (M, K)).astype(np.int8))
+        b_t = dev(rng.integers(-128, 128, (N, K)).astype(np.int8))
+        bias_t = dev(rng.integers(-50000, 50001, N).astype(np.int32))
+        outs = []
+        for which in ("workspace", "noalloc", "none"):
+            c_t = torch.full((M, N), 77, dtype=torch.int8, device="cuda")
+            p = capi.fpAintB_problem(a_t.data_ptr(), b_t.data_ptr(), None, c_t.data_ptr(), M, N, K, a_dtype=capi.I8, b_dtype=capi.I8,
+                                     c_dtype=capi.I8, epilogue=capi.EPI_ADD_RELU_MUL_CLAMP, requant=2e-4, d0=bias_t.data_ptr())
+            need = capi.workspace_bytes(p)
+            assert capi.kernel_name(p) == kernel and 0 < need <= capi.NOALLOC_SCRATCH_BYTES
+            if which == "workspace":
+                ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+                capi.launch(p, ws.data_ptr(), st)
+            elif which == "noalloc":
+                capi.launch_noalloc(p, st)
+            else:
+                capi.launch(p, None, st)
+            torch.cuda.synchronize()
+            outs.append(c_t.cpu().numpy().copy())
+        np.testing.assert_array_equal(outs[1], outs[0])
+        np.testing.assert_array_equal(outs[2], outs[0])
+        assert np.unique(outs[0]).size > 20
