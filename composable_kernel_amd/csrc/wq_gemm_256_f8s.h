@@ -229,7 +229,7 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
     [[maybe_unused]] const float* tab_a = (const float*)(lds + T::TAB_A);
     [[maybe_unused]] const float* tab_b = (const float*)(lds + T::TAB_B) + wave * T::TAB_LD;
     [[maybe_unused]] float s_lo = 0.f, s_hi = 0.f, s_lo_next = 0.f, s_hi_next = 0.f; // a_scale * b_scale of rows 0..127 / 128..255
-    [[maybe_unused]] f4_t pend0 = {0.f, 0.f, 0.f, 0.f}, pend1 = {0.f, 0.f, 0.f, 0.f}; // block sums of the previous row block, not yet folded in
+    [[maybe_unused]] f4_t pend0[2], pend1[2]; // block sums of this and the previous row block (by row block parity), not yet folded in
     if constexpr(ABSCALE)
     {
         // FNUZ bytes are multiplied as twice their value: their 2^-1 rides on the activation scales
@@ -397,18 +397,15 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
             }
             if constexpr(ABSCALE)
             {
-                // The block sums of row block mt - 1 are folded in now, a row block after their MFMAs were issued, so that the fused
-                // multiply-adds do not wait for a result (the last row block of a tile folds its own: nothing crosses the tile boundary).
-                if constexpr(mt > 0)
-                {
-                    constexpr int pm = mt - 1;
-                    const float ps   = ROWSCALE ? s_hi * s_lo : pm < MT / 2 ? s_lo : s_hi; // (row form: s_hi = the row scale read a row block ago)
-                    const f4_t sv    = {ps, ps, ps, ps};
-                    acc[0][pm]       = __builtin_elementwise_fma(pend0, sv, acc[0][pm]);
-                    acc[1][pm]       = __builtin_elementwise_fma(pend1, sv, acc[1][pm]);
-                }
+                // Every row block's MFMAs start from zero and write one of two register sets (by row block parity); the sums of
+                // row block mt - 1 are folded into the accumulators behind this row block's MFMAs, a whole row block after they
+                // were issued, so that the fused multiply-adds neither wait for a result nor hold back the next MFMAs (the last
+                // row block of a tile folds its own: nothing crosses the tile boundary).
+                constexpr int cur = mt & 1, prv = cur ^ 1;
                 if constexpr(mt == 0)
                     s_lo = s_lo_next, s_hi = s_hi_next;
+                // (row form: s_hi = the row scale read a row block ago)
+                [[maybe_unused]] const float ps = mt == 0 ? 0.f : ROWSCALE ? s_hi * s_lo : (mt - 1) < MT / 2 ? s_lo : s_hi;
                 if constexpr(ROWSCALE)
                     s_hi = row_s[16 * mt]; // this row block's row scale: used when its sums are folded in
                 if constexpr(mt == MT / 2)
@@ -421,24 +418,27 @@ __device__ __forceinline__ void f8s_kernel_body(const GemmParams& p)
                         s_lo_next = tab_a[2 * (t + 1)] * sbn, s_hi_next = tab_a[2 * (t + 1) + 1] * sbn;
                 }
                 const f4_t zero = {0.f, 0.f, 0.f, 0.f};
-                pend0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], zero, 1, 0, 0, 0, 0, 0);
-                pend1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], zero, 1, 0, 0, 0, 0, 0);
+                pend0[cur] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][0], af[w], zero, 1, 0, 0, 0, 0, 0);
+                pend1[cur] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[P][1], af[w], zero, 1, 0, 0, 0, 0, 0);
+                if constexpr(mt > 0)
+                {
+                    const f4_t sv   = {ps, ps, ps, ps};
+                    acc[0][mt - 1] = __builtin_elementwise_fma(pend0[prv], sv, acc[0][mt - 1]);
+                    acc[1][mt - 1] = __builtin_elementwise_fma(pend1[prv], sv, acc[1][mt - 1]);
+                }
                 if constexpr(!(PROBE & 1))
                     convert_half(wf[Q], raw[Q], std::integral_constant<int, mt>{});
                 if constexpr(mt == MT - 1) // (nothing is carried across the tile boundary)
                 {
                     const float ls = ROWSCALE ? s_hi * s_lo : s_hi;
                     const f4_t sv  = {ls, ls, ls, ls};
-                    acc[0][mt]    = __builtin_elementwise_fma(pend0, sv, acc[0][mt]);
-                    acc[1][mt]    = __builtin_elementwise_fma(pend1, sv, acc[1][mt]);
+                    acc[0][mt]    = __builtin_elementwise_fma(pend0[cur], sv, acc[0][mt]);
+                    acc[1][mt]    = __builtin_elementwise_fma(pend1[cur], sv, acc[1][mt]);
                 }
-                // (the four pending fused multiply-adds behind the fragment reads, the conversion behind the MFMAs)
+                // (both MFMAs first, the fragment reads and all of the row block's vector work in their shadow: measured best)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             else if constexpr(!(PROBE & 16))

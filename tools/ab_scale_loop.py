@@ -34,4 +34,11 @@ assert capi.is_supported(p), capi.lib.wqgemm_last_error().decode()
 for _ in range(n):
     capi.launch(p, None, sp)
 torch.cuda.synchronize()
-print(capi.kernel_name(p), n, "launches")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(n):
+    capi.launch(p, None, sp)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / n
+print(capi.kernel_name(p), 2 * n, f"launches; second half: {us:.1f} us per launch = {2.0 * M * N * K / us * 1e-6:.0f} TFLOP/s")
